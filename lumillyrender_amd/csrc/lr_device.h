@@ -1,0 +1,84 @@
+// lr_device.h -- HBM layouts shared by the kernels and the C ABI implementation.
+//
+// Scene blob (read-only, replicated per GPU; DESIGN.md "data layout in HBM"):
+//   nodes   4 x float4 per BVH node (64 B): x-row, y-row, z-row = {l.min, l.max, r.min, r.max}, then
+//           {child0, child1, -, -} as int bits.  child >= 0 inner, child < 0 leaf ~c = first<<3 | count.
+//   prims   3 x float4 per primitive (48 B) IN LEAF ORDER, so a leaf reads consecutive rows:
+//             triangle  {p0.xyz, id} {e1.xyz, -} {e2.xyz, -}     e1 = p1-p0, e2 = p2-p0 (triangle.rs:71-72)
+//             sphere    {c.xyz, id | 1<<31} {r, r*r, -, -} {-}
+//   shade   1 x float4 per primitive id: {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
+//   mats    3 x float4 per material: {color.rgb, type} {emission.rgb, weight} {param0..2, -}
+//   emit    3 x float4 per emitter (objects.rs:19-24, instance order):
+//             {p0|c .xyz, type} {p1.xyz | r, pdf} {p2.xyz, cumulative area}
+//   texels  float4 per IBL texel (rgb, -)
+//
+// Path state (SoA, one entry per resident path slot; every slot always carries a live path because
+// a finished path regenerates the next sample in place):
+//   ray_o {o.xyz, depth as int (-1 = slot retired)}   ray_d {d.xyz, camera g_term}
+//   hit   {t, primitive id as int (-1 = miss)}
+//   thr   {throughput.rgb, pixel index}               rad {radiance of this sample.rgb, sample index}
+//   acc   {sum over the current chunk.rgb, work item}
+//   sh_d  {shadow dir.xyz, distance to the light point} sh_w {weight.rgb, -}
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lumilly_hip.h"
+
+namespace lr {
+
+constexpr int kBlock = 256;            // 4 waves of 64
+constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
+constexpr int kNumShadeQueues = 6;
+constexpr int kQShadow = 6;
+constexpr int kCountersPerParity = 8;
+
+enum StatSlot { ST_SAMPLES = 0, ST_SEGMENTS, ST_SHADOW, ST_NODE_VISITS, ST_PRIM_TESTS, ST_SKY, ST_COUNT };
+
+struct DevCamera {
+  int type; int res_w, res_h;
+  float forward[3], right[3], up[3], position[3], aperture_position[3];
+  float sensor_w, sensor_h;
+  float aperture_sensor_distance, aperture_radius, focus_distance, sensor_pixel_area;
+  float weight2;                       // sensor_sensitivity / (sensor pdf * aperture pdf)  (main.rs:101,118)
+};
+
+struct DevScene {
+  const float4* nodes;
+  const float4* prims;
+  const float4* shade;
+  const float4* mats;
+  const float4* emit;
+  const float4* texels;
+  const uint8_t* prim_qid;             // per primitive id: shade queue (= material type)
+  int   n_emitters;
+  float emission_area;
+  int   sky_type;
+  float sky_color[3];
+  int   sky_h;
+  float sky_lon;
+  DevCamera cam;
+};
+
+struct DevParams {
+  int integrator, spp; uint32_t seed; int depth, depth_limit, no_direct_emitter;
+};
+
+struct DevState {
+  float4* ray_o; float4* ray_d; float2* hit;
+  float4* thr;   float4* rad;   float4* acc;
+  float4* sh_d;  float4* sh_w;
+  uint32_t* queues;                    // (kNumShadeQueues + 1) * n_slots slot indices
+  uint32_t* counters;                  // 2 parities * kCountersPerParity
+  uint32_t* next_item;                 // work-item dispenser
+  uint32_t* n_retired;                 // slots that found the dispenser empty
+  unsigned long long* stats;           // ST_COUNT
+  float4* partial;                     // n_items chunk sums
+  float*  film;                        // W*H*3
+  const int4* tiles;                   // x0, y0, w, h
+  const uint32_t* tile_prefix;         // n_tiles + 1
+  int n_tiles;
+  uint32_t n_slots, n_pix, n_chunks, chunk_spp, n_items;
+  int stack_depth;                     // LDS traversal stack entries per lane
+};
+
+}  // namespace lr

@@ -1,0 +1,778 @@
+// lr_kernels.h -- the wavefront path-tracing kernels for gfx950 (wave64, 256-thread workgroups).
+//
+// One iteration of the render loop is   trace -> shade<bsdf> (one launch per BSDF present, plus
+// the miss/sky launch) -> shadow.   Paths never leave their slot: a path that ends regenerates
+// the next camera sample of its work item in place, so every slot is live until the work-item
+// dispenser runs dry ("persistent" path slots; workgroups are grid-strided over them).
+//
+//   k_generate   camera.rs:64-115 / :411-476 / :168-188   first camera sample of every slot
+//   k_trace      bvh.rs:130-141 + aabb.rs:74-92 + triangle.rs:69-100 + sphere.rs:42-63
+//                closest hit; LDS-staged per-lane traversal stack; epilogue compacts slot ids into
+//                one queue per BSDF with __ballot / popcount prefix sums
+//   k_shade<M>   scene.rs:153-193 (emission, Russian roulette, direct-light sample, BSDF sample),
+//                material/*.rs for M, sky.rs for the miss queue, main.rs:92-121 for the per-sample
+//                accumulation; pushes NEE-eligible slots to the shadow queue
+//   k_shadow     scene.rs:127-147: visibility by closest hit within EPS of the sampled point,
+//                light-side cosine and emission of the surface actually hit
+//   k_resolve    main.rs:104,121 + img.rs:25-27: chunk sums -> pixel mean -> film
+#pragma once
+#include "lr_math.h"
+#include "lr_device.h"
+
+namespace lr {
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------
+LR_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+LR_DEV uint32_t rank_in_mask(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Reserve popcount(pred) consecutive entries with ONE atomic per wave; returns this lane's index.
+// Must be reached by the whole (converged) wave.
+LR_DEV uint32_t wave_reserve(uint32_t* counter, bool pred, uint64_t* mask_out = nullptr) {
+  uint64_t mask = __ballot(pred);
+  if (mask_out) *mask_out = mask;
+  if (mask == 0) return 0;
+  uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+  uint32_t base = 0;
+  if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+  base = __shfl(base, (int)leader, 64);
+  return base + rank_in_mask(mask);
+}
+LR_DEV void queue_push(uint32_t* queue, uint32_t* counter, bool pred, uint32_t value) {
+  uint32_t idx = wave_reserve(counter, pred);
+  if (pred) queue[idx] = value;
+}
+LR_DEV void wave_stat_add(unsigned long long* stat, uint32_t v) {
+  // sum over the wave, one atomic
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if (lane_id() == 0 && v) atomicAdd(stat, (unsigned long long)v);
+}
+
+// ------------------------------------------------------------------------------------------
+// primitive tests -- exact restatements (no contraction in this TU)
+// ------------------------------------------------------------------------------------------
+// triangle.rs:69-100 with e1, e2 precomputed
+LR_DEV bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
+  V3 pv = cross(d, e2);
+  float det = dot(e1, pv);
+  if (__builtin_fabsf(det) < kEps) return false;
+  float invdet = 1.0f / det;
+  V3 tv = o - p0;
+  float u = dot(tv, pv) * invdet;
+  if (u < 0.0f || u > 1.0f) return false;
+  V3 qv = cross(tv, e1);
+  float v = dot(d, qv) * invdet;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  float t = dot(e2, qv) * invdet;
+  if (t < kEps) return false;
+  *t_out = t;
+  return true;
+}
+// sphere.rs:42-55
+LR_DEV bool sphere_test(V3 c, float r2, V3 o, V3 d, float* t_out) {
+  V3 co = o - c;
+  float cod = dot(co, d);
+  float det = cod * cod - sqr_norm(co) + r2;
+  if (det <= 0.0f) return false;
+  float sq = __builtin_sqrtf(det);
+  float t1 = -cod - sq;
+  float t2 = -cod + sq;
+  if (t1 < kEps && t2 < kEps) return false;
+  *t_out = t1 > kEps ? t1 : t2;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH traversal.  Closest hit = min t over all primitives whose own test accepts, ties to the
+// lowest primitive id (order independent).  Boxes are padded by the host builder, so the slab
+// test may use fused / approximate arithmetic: it only prunes, never decides.
+//   SHADOW: accept only hits with t - dist <= EPS; stop at the first hit with t - dist < -EPS
+//   (then the closest hit is at least that near and scene.rs:129 rejects the connection).
+// ------------------------------------------------------------------------------------------
+struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; };
+
+template <bool SHADOW>
+LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t* stk_n, float* stk_t) {
+  TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = 0;
+  float cull = SHADOW ? dist + 2.0f * kEps : 3.0e38f;       // box-pruning bound
+  float ix, iy, iz, ox, oy, oz;
+  {
+#pragma clang fp contract(fast)
+    // a zero direction component would give inf * 0 = NaN below, and a NaN beside an inf makes the
+    // min/max chain reject boxes the ray is inside of; 1e-20 is "parallel" at any scene scale and
+    // keeps every product finite, so the test stays conservative
+    float dx = __builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x;
+    float dy = __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y;
+    float dz = __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z;
+    ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz);
+    ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+  }
+  const uint32_t tid = threadIdx.x;
+  int cur = 0, sp = 0;
+  while (true) {
+    if (cur >= 0) {
+      const float4* n = sc.nodes + 4 * (size_t)cur;
+      float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
+      res.visits += 2;
+      float lmin, lmax, rmin, rmax;
+      {
+#pragma clang fp contract(fast)
+        float a0 = __builtin_fmaf(nx.x, ix, ox), a1 = __builtin_fmaf(nx.y, ix, ox);
+        float b0 = __builtin_fmaf(ny.x, iy, oy), b1 = __builtin_fmaf(ny.y, iy, oy);
+        float c0 = __builtin_fmaf(nz.x, iz, oz), c1 = __builtin_fmaf(nz.y, iz, oz);
+        lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
+        lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), cull));
+        float d0 = __builtin_fmaf(nx.z, ix, ox), d1 = __builtin_fmaf(nx.w, ix, ox);
+        float e0 = __builtin_fmaf(ny.z, iy, oy), e1 = __builtin_fmaf(ny.w, iy, oy);
+        float f0 = __builtin_fmaf(nz.z, iz, oz), f1 = __builtin_fmaf(nz.w, iz, oz);
+        rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
+        rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), cull));
+      }
+      bool hl = lmin <= lmax, hr = rmin <= rmax;
+      int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
+      if (hl && hr) {
+        bool swap = rmin < lmin;
+        int nearc = swap ? cr : cl, farc = swap ? cl : cr;
+        float fart = swap ? lmin : rmin;
+        stk_n[sp * kBlock + tid] = (uint32_t)farc;
+        stk_t[sp * kBlock + tid] = fart;
+        ++sp;
+        cur = nearc;
+        continue;
+      } else if (hl) { cur = cl; continue; }
+      else if (hr) { cur = cr; continue; }
+    } else {
+      uint32_t enc = (uint32_t)~cur;
+      uint32_t first = enc >> 3, count = enc & 7u;
+      for (uint32_t k = 0; k < count; ++k) {
+        const float4* q = sc.prims + 3 * (size_t)(first + k);
+        float4 q0 = q[0], q1 = q[1];
+        uint32_t idw = __float_as_uint(q0.w);
+        int id = (int)(idw & 0x7fffffffu);
+        float t; bool hit;
+        res.tests += 1;
+        if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+        else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t); }
+        if (!hit) continue;
+        if (SHADOW) {
+          float diff = t - dist;
+          if (diff < -kEps) { res.occluded = true; return res; }
+          if (diff > kEps) continue;
+        }
+        if (t < res.t || (t == res.t && id < res.prim)) {
+          res.t = t; res.prim = id;
+          cull = t;
+        }
+      }
+    }
+    // pop the next subtree that can still contain a closer hit
+    bool found = false;
+    while (sp > 0) {
+      --sp;
+      float pt = stk_t[sp * kBlock + tid];
+      if (pt <= cull) { cur = (int)stk_n[sp * kBlock + tid]; found = true; break; }
+    }
+    if (!found) break;
+  }
+  return res;
+}
+
+// ------------------------------------------------------------------------------------------
+// util.rs
+// ------------------------------------------------------------------------------------------
+LR_DEV void orthonormal_basis(V3 w, V3* t_out, V3* b_out) {            // util.rs:12-21
+  V3 a = __builtin_fabsf(w.x) > kEps ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+  V3 tangent = normalize(cross(a, w));
+  *t_out = tangent; *b_out = cross(w, tangent);
+}
+LR_DEV V3 reflect(V3 self, V3 normal) { return -self + normal * (dot(self, normal) * 2.0f); }   // util.rs:30-32
+LR_DEV bool refract(V3 self, V3 normal, float from_per_to_ior, V3* out) {                       // util.rs:34-42
+  float dn = dot(self, normal);
+  float cos2theta = 1.0f - (from_per_to_ior * from_per_to_ior) * (1.0f - (dn * dn));
+  if (cos2theta > 0.0f) {
+    *out = -self * from_per_to_ior - normal * (from_per_to_ior * -dn + __builtin_sqrtf(cos2theta));
+    return true;
+  }
+  return false;
+}
+LR_DEV V3 orienting_normal(V3 out_, V3 normal) {                       // lambert.rs:14-21
+  if (dot(normal, out_) < 0.0f) return normal * -1.0f;
+  return normal;
+}
+
+// ------------------------------------------------------------------------------------------
+// materials.  Mat = the three float4 rows of the material table.
+// ------------------------------------------------------------------------------------------
+struct Mat { float4 m0, m1, m2; };
+LR_DEV V3 mcolor(const Mat& m) { return v3(m.m0); }
+
+LR_DEV float signed_mod(float base, float module) {                    // lambert.rs:58-64
+  if (base > 0.0f) return det_fmod_pos(base, module);
+  return module - det_fmod_pos(-base, module);
+}
+LR_DEV float checker(float u, float v) {                               // lambert.rs:66-90 (grey level)
+  const float lw = 2.0f, li = 150.0f, sw = 1.0f, si = 30.0f, cw = 150.0f, ci = 300.0f;
+  float lu = signed_mod(u, li), lv = signed_mod(v, li);
+  float su = signed_mod(u, si), sv = signed_mod(v, si);
+  float cu = signed_mod(u, ci), cv = signed_mod(v, ci);
+  if (lu < lw || lv < lw) return 0.5f;
+  else if (su < sw || sv < sw) return 0.6f;
+  else if ((cu < cw || cv < cw) && !(cu < cw && cv < cw)) return 0.8f;
+  return 1.0f;
+}
+LR_DEV float ggx_g(float alpha, V3 v, V3 n) {                          // ggx.rs:27-32
+  float a2 = alpha * alpha;
+  float c = dot(v, n);
+  float tan = 1.0f / (c * c) - 1.0f;
+  return 2.0f / (1.0f + __builtin_sqrtf(1.0f + a2 * tan * tan));
+}
+LR_DEV float ggx_ndf(float alpha, V3 mm, V3 n) {                       // ggx.rs:34-39
+  float a2 = alpha * alpha;
+  float mdn = dot(mm, n);
+  float x = (a2 - 1.0f) * mdn * mdn + 1.0f;
+  return a2 / (kPi * x * x);
+}
+LR_DEV float ggx_fresnel(float ior, V3 in_, V3 mm) {                   // ggx.rs:41-47
+  float nnn = 1.0f - ior, nnp = 1.0f + ior;
+  float f_0 = (nnn * nnn) / (nnp * nnp);
+  float c = dot(in_, mm);
+  float c1 = 1.0f - c;
+  float c2 = c1 * c1, c4 = c2 * c2;                                    // powi(5) = c1 * (c1^2)^2
+  return f_0 + (1.0f - f_0) * (c1 * c4);
+}
+LR_DEV void ior_pair(float ior, V3 out_, V3 n, float* from_ior, float* to_ior) {   // ideal_refraction.rs:117-135
+  if (dot(out_, n) > 0.0f) { *from_ior = 1.0f; *to_ior = ior; }
+  else { *from_ior = ior; *to_ior = 1.0f; }
+}
+LR_DEV float fresnel_exact(float n1, float n2, V3 out_, V3 in_, V3 on) {           // ideal_refraction.rs:137-149
+  float cos1 = dot(out_, on);
+  float cos2 = dot(in_, -on);
+  float a = (n1 * cos1 - n2 * cos2) / (n1 * cos1 + n2 * cos2);
+  float b = (n1 * cos2 - n2 * cos1) / (n1 * cos2 + n2 * cos1);
+  return (a * a + b * b) / 2.0f;
+}
+
+template <int MT>
+LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
+  if (MT == LR_MAT_LAMBERT) {                                          // lambert.rs:32-35
+    float g = checker(pos.x, pos.z);
+    return mcolor(m) * v3(g, g, g) / kPi;
+  } else if (MT == LR_MAT_PHONG) {                                     // phong.rs:37-45
+    V3 on = orienting_normal(out_, n);
+    if (dot(in_, on) <= 0.0f) return v3(0, 0, 0);
+    V3 r = reflect(out_, on);
+    float c = dot(r, in_);
+    float a = m.m2.x;
+    return mcolor(m) * ((a + 2.0f) / (2.0f * kPi) * det_pow(c, a));
+  } else if (MT == LR_MAT_BLINN_PHONG) {                               // blinn_phong.rs:37-47
+    V3 on = orienting_normal(out_, n);
+    if (dot(in_, on) <= 0.0f) return v3(0, 0, 0);
+    V3 h = normalize(in_ + out_);
+    float c = dot(h, on);
+    float a = m.m2.x;
+    return mcolor(m) * ((a + 2.0f) * (a + 4.0f) / (8.0f * kPi * (det_pow(2.0f, -a / 2.0f) + a)) * det_pow(c, a));
+  } else if (MT == LR_MAT_GGX) {                                       // ggx.rs:71-85
+    V3 on = orienting_normal(out_, n);
+    if (dot(in_, on) <= 0.0f) return v3(0, 0, 0);
+    V3 h = normalize(in_ + out_);
+    float alpha = m.m2.x * m.m2.x;
+    float f = ggx_fresnel(m.m2.y, in_, h);
+    float g = ggx_g(alpha, in_, on) * ggx_g(alpha, out_, on);
+    float d = ggx_ndf(alpha, h, on);
+    return mcolor(m) * f * g * d / (4.0f * dot(in_, on) * dot(out_, on));
+  } else {                                                             // ideal_refraction.rs:39-66
+    V3 on = orienting_normal(out_, n);
+    float from_ior, to_ior; ior_pair(m.m2.x, out_, n, &from_ior, &to_ior);
+    float ratio = from_ior / to_ior;
+    V3 r;
+    if (refract(out_, on, ratio, &r)) {
+      float fr = fresnel_exact(from_ior, to_ior, out_, r, on);
+      if (dot(in_, on) > 0.0f) return mcolor(m) * 1.0f / dot(in_, n) * fr;
+      float q = to_ior / from_ior;
+      float ft = (1.0f - fr) * (q * q);
+      return mcolor(m) * 1.0f / dot(in_, n) * ft;
+    }
+    return mcolor(m) * 1.0f / dot(in_, n);
+  }
+}
+
+template <int MT>
+LR_DEV void material_sample(const Mat& m, V3 out_, V3 n, const float* xi, V3* in_out, float* pdf_out) {
+  if (MT == LR_MAT_LAMBERT) {                                          // lambert.rs:37-55, util.rs:87-96
+    V3 on = orienting_normal(out_, n);
+    V3 w = on, u, v; orthonormal_basis(w, &u, &v);
+    float r1 = 2.0f * kPi * xi[0];
+    float r2 = xi[1];
+    float r2s = __builtin_sqrtf(r2);
+    float s1, c1; det_sincos(r1, &s1, &c1);
+    V3 s = v3(c1 * r2s, s1 * r2s, __builtin_sqrtf(1.0f - r2));
+    V3 in_ = u * s.x + v * s.y + w * s.z;
+    *in_out = in_; *pdf_out = dot(in_, n) / kPi;
+  } else if (MT == LR_MAT_PHONG) {                                     // phong.rs:47-68
+    V3 on = orienting_normal(out_, n);
+    float a = m.m2.x;
+    V3 r = reflect(out_, on);
+    V3 w = r, u, v; orthonormal_basis(w, &u, &v);
+    float r1 = 2.0f * kPi * xi[0];
+    float r2 = xi[1];
+    float t = det_pow(r2, 1.0f / (a + 2.0f));
+    float ts = __builtin_sqrtf(1.0f - t * t);
+    float s1, c1; det_sincos(r1, &s1, &c1);
+    V3 in_ = u * c1 * ts + v * s1 * ts + w * t;
+    float c = dot(r, in_);
+    *in_out = in_; *pdf_out = (a + 2.0f) / (2.0f * kPi) * det_pow(c, a);
+  } else if (MT == LR_MAT_BLINN_PHONG) {                               // blinn_phong.rs:49-72
+    V3 on = orienting_normal(out_, n);
+    float a = m.m2.x;
+    V3 w = on, u, v; orthonormal_basis(w, &u, &v);
+    float r1 = 2.0f * kPi * xi[0];
+    float r2 = xi[1];
+    float t = det_pow(r2, 1.0f / (a + 2.0f));
+    float ts = __builtin_sqrtf(1.0f - t * t);
+    float s1, c1; det_sincos(r1, &s1, &c1);
+    V3 h = u * c1 * ts + v * s1 * ts + w * t;
+    V3 in_ = h * (2.0f * dot(out_, h)) - out_;
+    float c = dot(on, h);
+    *in_out = in_; *pdf_out = (a + 2.0f) / (2.0f * kPi) * det_pow(c, a);
+  } else if (MT == LR_MAT_GGX) {                                       // ggx.rs:87-113
+    V3 on = orienting_normal(out_, n);
+    V3 w = on, u, v; orthonormal_basis(w, &u, &v);
+    float alpha = m.m2.x * m.m2.x;
+    float r1 = 2.0f * kPi * xi[0];
+    float r2 = xi[1];
+    float tan = alpha * __builtin_sqrtf(r2 / (1.0f - r2));
+    float x = 1.0f + tan * tan;
+    float c = 1.0f / __builtin_sqrtf(x);
+    float s = tan / __builtin_sqrtf(x);
+    float s1, c1; det_sincos(r1, &s1, &c1);
+    V3 h = u * c1 * s + v * s1 * s + w * c;
+    float o_h = dot(out_, h);
+    V3 in_ = h * (2.0f * o_h) - out_;
+    float jacobian = 1.0f / (4.0f * o_h);
+    *in_out = in_; *pdf_out = ggx_ndf(alpha, h, on) * dot(h, on) * jacobian;
+  } else {                                                             // ideal_refraction.rs:68-104
+    float from_ior, to_ior; ior_pair(m.m2.x, out_, n, &from_ior, &to_ior);
+    float ratio = from_ior / to_ior;
+    V3 on = orienting_normal(out_, n);
+    V3 r;
+    if (refract(out_, on, ratio, &r)) {
+      float fr = fresnel_exact(from_ior, to_ior, out_, r, on);
+      if (xi[2] < fr) { *in_out = reflect(out_, on); *pdf_out = 1.0f * fr; }
+      else { *in_out = r; *pdf_out = 1.0f * (1.0f - fr); }
+    } else { *in_out = reflect(out_, on); *pdf_out = 1.0f; }
+  }
+}
+
+template <int MT>
+LR_DEV V3 material_coef(const Mat& m, V3 out_, V3 n, float fly_distance) {   // traits.rs:20-22, ideal_refraction.rs:106-113
+  if (MT == LR_MAT_IDEAL_REFRACTION) {
+    if (dot(out_, n) < 0.0f) {
+      V3 v = -(v3(1.0f, 1.0f, 1.0f) - mcolor(m)) * m.m2.y * fly_distance;
+      return v3(det_exp(v.x), det_exp(v.y), det_exp(v.z));
+    }
+  }
+  return v3(1.0f, 1.0f, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// cameras  (camera.rs)
+// ------------------------------------------------------------------------------------------
+LR_DEV V3 arr3(const float* a) { return v3(a[0], a[1], a[2]); }
+
+LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* o_out, V3* d_out, float* g_out) {
+  V3 position = arr3(c.position), right = arr3(c.right), up = arr3(c.up);
+  V3 aperture_position = arr3(c.aperture_position);
+  if (c.type == LR_CAMERA_IDEAL_PINHOLE) {                             // camera.rs:64-115
+    float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
+    float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
+    V3 point = position - right * px + up * py;
+    *o_out = aperture_position;
+    *d_out = normalize(aperture_position - point);
+    *g_out = 1.0f;
+  } else if (c.type == LR_CAMERA_THIN_LENS) {                          // camera.rs:411-476
+    V3 forward = arr3(c.forward);
+    float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
+    float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
+    V3 point = position - right * px + up * py;
+    float au = 2.0f * kPi * d.v[2];
+    float av = __builtin_sqrtf(d.v[3]) * c.aperture_radius;
+    float s1, c1; det_sincos(au, &s1, &c1);
+    float apx = c1 * av, apy = s1 * av;
+    V3 apoint = aperture_position + right * apx + up * apy;
+    V3 sensor_center = aperture_position - point;
+    V3 object_plane = sensor_center * (c.focus_distance / dot(sensor_center, forward));
+    *o_out = apoint;
+    *d_out = normalize(aperture_position + object_plane - apoint);
+    V3 dir = normalize(apoint - point);                                // geometry_term :446-455
+    float cos_term = dot(dir, forward);
+    float dd = c.aperture_sensor_distance / cos_term;
+    *g_out = cos_term * cos_term / (dd * dd);
+  } else {                                                             // camera.rs:168-188
+    float p = ((float)x + d.v[0]) / (float)c.res_w * kPi * 2.0f;
+    float t = ((float)y + d.v[1]) / (float)c.res_h * kPi;
+    float sp, cp, st, ct; det_sincos(p, &sp, &cp); det_sincos(t, &st, &ct);
+    *o_out = aperture_position;
+    *d_out = v3(st * cp, st * sp, ct);
+    *g_out = 1.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// sky  (sky.rs)
+// ------------------------------------------------------------------------------------------
+LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
+  if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
+  float theta = det_acos(dir.y);                                       // sky.rs:57-78
+  float phi = det_atan2(dir.z, dir.x);
+  float uu = (phi + kPi + sc.sky_lon) / (2.0f * kPi);
+  float u = uu >= 0.0f ? det_fmod_pos(uu, 1.0f) : -det_fmod_pos(-uu, 1.0f);
+  float vv = theta / kPi;
+  float v = vv >= 0.0f ? det_fmod_pos(vv, 1.0f) : -det_fmod_pos(-vv, 1.0f);
+  uint32_t height = (uint32_t)sc.sky_h, width = height * 2u;
+  uint64_t all = (uint64_t)width * height;
+  float fx = __builtin_floorf((float)width * u), fy = __builtin_floorf((float)height * v);
+  uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates
+  uint64_t index = (y * width + x) % all;
+  return v3(sc.texels[index]);
+}
+
+// ------------------------------------------------------------------------------------------
+// emitter sampling  (objects.rs:37-51, triangle.rs:140-149, sphere.rs:79-84, util.rs:108-116)
+// ------------------------------------------------------------------------------------------
+LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float* pdf) {
+  float roulette = sc.emission_area * d.v[1];
+  int k = 0;
+  // first k with roulette <= cumulative area (the host accumulates in the reference's order)
+  int n = sc.n_emitters;
+  if (n <= 8) {
+    while (k < n - 1 && !(roulette <= sc.emit[3 * k + 2].w)) ++k;
+  } else {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (roulette <= sc.emit[3 * mid + 2].w) hi = mid; else lo = mid + 1; }
+    k = lo;
+  }
+  float4 e0 = sc.emit[3 * k], e1 = sc.emit[3 * k + 1], e2 = sc.emit[3 * k + 2];
+  if (__float_as_uint(e0.w) == LR_PRIM_TRIANGLE) {
+    float u = d.v[2], v = d.v[3];
+    float mn = fmin_rs(u, v), mx = fmax_rs(u, v);
+    *value = v3(e0) * mn + v3(e1) * (1.0f - mx) + v3(e2) * (mx - mn);
+  } else {
+    float r1 = 2.0f * kPi * d.v[2];
+    float r2 = d.v[3] * 2.0f - 1.0f;
+    float r2s = __builtin_sqrtf(1.0f - r2 * r2);
+    float s1, c1; det_sincos(r1, &s1, &c1);
+    *value = v3(e0) + e1.x * v3(c1 * r2s, s1 * r2s, r2);
+  }
+  *pdf = e1.w;
+}
+
+LR_DEV float russian_roulette(float init, int d, const DevParams& rp) {   // scene.rs:64-76
+  float p = init;
+  if (d > rp.depth_limit) {
+    int k = d - rp.depth_limit;
+    float h = 1.0f;                                                     // 0.5^k, exact
+    for (int i = 0; i < k && i < 200; ++i) h = h * 0.5f;
+    p = p * h;
+  }
+  if (d <= rp.depth && p > 0.0f) p = 1.0f;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// work items: item = chunk * n_pix + pixel rank; pixel rank -> (x, y) through the tile list
+// ------------------------------------------------------------------------------------------
+LR_DEV uint32_t item_pixel(const DevState& st, const DevCamera& cam, uint32_t rank) {
+  int lo = 0, hi = st.n_tiles - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (st.tile_prefix[mid] <= rank) lo = mid; else hi = mid - 1; }
+  int4 t = st.tiles[lo];
+  uint32_t off = rank - st.tile_prefix[lo];
+  uint32_t x = (uint32_t)t.x + off % (uint32_t)t.z, y = (uint32_t)t.y + off / (uint32_t)t.z;
+  return y * (uint32_t)cam.res_w + x;
+}
+
+// Start the camera sample (pixel, sample) in `slot`.
+LR_DEV void start_sample(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, uint32_t pixel, uint32_t sample) {
+  Draw4 d0 = rng_block(rp.seed, pixel, sample, 0u);
+  int x = (int)(pixel % (uint32_t)sc.cam.res_w), y = (int)(pixel / (uint32_t)sc.cam.res_w);
+  V3 o, d; float g;
+  camera_sample(sc.cam, x, y, d0, &o, &d, &g);
+  st.ray_o[slot] = make_float4(o.x, o.y, o.z, __int_as_float(0));
+  st.ray_d[slot] = make_float4(d.x, d.y, d.z, g);
+  st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
+  st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
+}
+
+// End-of-path bookkeeping for the whole wave (main.rs:92-121): fold the finished sample into the
+// chunk sum, hand out new work items with one atomic per wave, start the next camera sample.
+//   finished : this lane's path just ended with radiance L (sample index `sample`, pixel `pixel`)
+//   fresh    : this lane has no work item yet (k_generate)
+LR_DEV void finish_and_regenerate(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot,
+                                  bool finished, bool fresh, V3 L, float g_term, uint32_t pixel, uint32_t sample) {
+  bool need_item = fresh;
+  uint32_t item = 0;
+  V3 sum = v3(0, 0, 0);
+  if (finished) {
+    float4 a = st.acc[slot];
+    item = __float_as_uint(a.w);
+    V3 delta = L;
+    if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (L * g_term) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
+    sum = v3(a) + delta;
+    sample += 1;
+    uint32_t chunk = item / st.n_pix;
+    uint32_t end = (chunk + 1) * st.chunk_spp;
+    if (end > (uint32_t)rp.spp) end = (uint32_t)rp.spp;
+    if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
+  }
+  uint64_t mask;
+  uint32_t new_item = wave_reserve(st.next_item, need_item, &mask);
+  bool retired = false;
+  if (need_item) {
+    if (new_item < st.n_items) {
+      item = new_item;
+      uint32_t rank = item % st.n_pix, chunk = item / st.n_pix;
+      pixel = item_pixel(st, sc.cam, rank);
+      sample = chunk * st.chunk_spp;
+      sum = v3(0, 0, 0);
+    } else retired = true;
+  }
+  if (finished || fresh) {
+    if (retired) {
+      st.ray_o[slot] = make_float4(0, 0, 0, __int_as_float(-1));
+    } else {
+      st.acc[slot] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(item));
+      start_sample(sc, st, rp, slot, pixel, sample);
+    }
+  }
+  uint32_t idx = wave_reserve(st.n_retired, retired);
+  (void)idx;
+}
+
+// ==========================================================================================
+// kernels
+// ==========================================================================================
+__global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, DevParams rp) {
+  uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t base = blockIdx.x * kBlock; base < st.n_slots; base += stride) {
+    uint32_t slot = base + threadIdx.x;
+    bool valid = slot < st.n_slots;
+    finish_and_regenerate(sc, st, rp, valid ? slot : 0, false, valid, v3(0, 0, 0), 1.0f, 0, 0);
+  }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, int parity) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* stk_n = lds;
+  float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
+  uint32_t* cnt = st.counters + parity * kCountersPerParity;
+  if (blockIdx.x == 0 && threadIdx.x < kCountersPerParity) st.counters[(parity ^ 1) * kCountersPerParity + threadIdx.x] = 0;   // next iteration's counters
+  uint32_t stride = gridDim.x * kBlock;
+  uint32_t n_seg = 0, n_vis = 0, n_tst = 0;
+  for (uint32_t base = blockIdx.x * kBlock; base < st.n_slots; base += stride) {
+    uint32_t slot = base + threadIdx.x;
+    bool active = false;
+    int qid = -1;
+    if (slot < st.n_slots) {
+      float4 ro = st.ray_o[slot];
+      if (__float_as_int(ro.w) >= 0) {
+        float4 rd = st.ray_d[slot];
+        active = true;
+        TraceResult r = traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
+        st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
+        qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
+        n_seg += 1;
+        if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
+      }
+    }
+    // compaction: one queue per BSDF (and one for misses), order-preserving within the wave
+    uint64_t todo = __ballot(active);
+    while (todo) {
+      int lead = (int)__builtin_ctzll(todo);
+      int q = __shfl(qid, lead, 64);
+      bool mine = active && qid == q;
+      queue_push(st.queues + (size_t)q * st.n_slots, cnt + q, mine, slot);
+      todo &= ~__ballot(mine);
+    }
+  }
+  wave_stat_add(st.stats + ST_SEGMENTS, n_seg);
+  if (COUNT) { wave_stat_add(st.stats + ST_NODE_VISITS, n_vis); wave_stat_add(st.stats + ST_PRIM_TESTS, n_tst); }
+}
+
+// MT in 0..4 = BSDF of the hit material; MT == kQMiss = sky
+template <int MT>
+__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevParams rp, int parity) {
+  uint32_t* cnt = st.counters + parity * kCountersPerParity;
+  const uint32_t n = cnt[MT];
+  const uint32_t* queue = st.queues + (size_t)MT * st.n_slots;
+  uint32_t* shadow_q = st.queues + (size_t)kQShadow * st.n_slots;
+  uint32_t stride = gridDim.x * kBlock;
+  uint32_t n_done = 0, n_sky = 0;
+  const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
+  for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    bool valid = i < n;
+    uint32_t slot = valid ? queue[i] : 0;
+    bool finished = false, has_shadow = false;
+    V3 L = v3(0, 0, 0); float g_term = 1.0f; uint32_t pixel = 0, sample = 0;
+    if (valid) {
+      float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
+      int depth = __float_as_int(ro.w);
+      pixel = __float_as_uint(th.w); sample = __float_as_uint(ra.w);
+      V3 o = v3(ro), d = v3(rd), T = v3(th);
+      L = v3(ra); g_term = rd.w;
+      if (MT == kQMiss) {                                              // scene.rs:29 / :43
+        L = L + T * sky_radiance(sc, d);
+        if (sc.sky_type == LR_SKY_IBL) n_sky += 1;
+        finished = true;
+      } else {
+        float2 h = st.hit[slot];
+        float t = h.x; int prim = __float_as_int(h.y);
+        V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
+        float4 sh = sc.shade[prim];
+        uint32_t mw = __float_as_uint(sh.w);
+        V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
+        uint32_t mi = mw & 0x7fffffffu;
+        Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
+        V3 out_ = -d;
+        V3 emission = v3(m.m1);
+        bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
+        if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
+          L = L + T * emission;
+        float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
+        Draw4 d1 = rng_block(rp.seed, pixel, sample, 1u + 2u * (uint32_t)depth);
+        if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
+          finished = true;
+        } else {
+          // ---- direct light (scene.rs:104-151), the occlusion test itself runs in k_shadow ----
+          if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
+            V3 lp; float lpdf;
+            sample_emission(sc, d1, &lp, &lpdf);
+            V3 direct_path = lp - pos;
+            float d2 = sqr_norm(direct_path);
+            float dist = __builtin_sqrtf(d2);
+            V3 dir = direct_path / dist;
+            V3 point_normal = orienting_normal(out_, nrm);
+            float point_cos = dot(dir, point_normal);
+            if (point_cos > 0.0f) {
+              V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
+              V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
+              st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
+              st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
+              has_shadow = true;
+            }
+          }
+          // ---- BSDF sample (scene.rs:78-102) ----
+          Draw4 d2r = rng_block(rp.seed, pixel, sample, 2u + 2u * (uint32_t)depth);
+          V3 in_; float pdf;
+          material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
+          V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
+          V3 coef = material_coef<MT>(m, out_, nrm, t);
+          float c = dot(in_, nrm);
+          V3 f = brdf * coef * c / pdf / p;
+          T = T * f;
+          st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
+          st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, g_term);
+          st.thr[slot] = make_float4(T.x, T.y, T.z, th.w);
+          st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
+        }
+      }
+    }
+    if (finished) n_done += 1;
+    finish_and_regenerate(sc, st, rp, slot, finished, false, L, g_term, pixel, sample);
+    queue_push(shadow_q, cnt + kQShadow, has_shadow, slot);
+  }
+  wave_stat_add(st.stats + ST_SAMPLES, n_done);
+  if (MT == kQMiss) wave_stat_add(st.stats + ST_SKY, n_sky);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, int parity) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* stk_n = lds;
+  float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
+  const uint32_t n = st.counters[parity * kCountersPerParity + kQShadow];
+  const uint32_t* queue = st.queues + (size_t)kQShadow * st.n_slots;
+  uint32_t stride = gridDim.x * kBlock;
+  uint32_t n_q = 0, n_vis = 0, n_tst = 0;
+  for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    if (i < n) {
+      uint32_t slot = queue[i];
+      // NOTE: shade already advanced ray_o to the hit point, which is the shadow ray origin (scene.rs:114-117)
+      float4 ro = st.ray_o[slot];
+      float4 sd = st.sh_d[slot];
+      V3 o = v3(ro), dir = v3(sd);
+      TraceResult r = traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
+      n_q += 1;
+      if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
+      if (!r.occluded && r.prim >= 0) {                                // scene.rs:127-131
+        V3 pos = o + dir * r.t;
+        float4 sh = sc.shade[r.prim];
+        uint32_t mw = __float_as_uint(sh.w);
+        V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
+        float light_cos = dot(-dir, light_normal);
+        if (light_cos > 0.0f) {                                        // scene.rs:133-139
+          V3 l_i = v3(sc.mats[3 * (mw & 0x7fffffffu) + 1]);           // emission of what was hit (scene.rs:144)
+          float4 w = st.sh_w[slot];
+          float4 ra = st.rad[slot];
+          V3 L = v3(ra) + v3(w) * l_i * light_cos;
+          st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
+        }
+      }
+    }
+  }
+  wave_stat_add(st.stats + ST_SHADOW, n_q);
+  if (COUNT) { wave_stat_add(st.stats + ST_NODE_VISITS, n_vis); wave_stat_add(st.stats + ST_PRIM_TESTS, n_tst); }
+}
+
+__global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, DevParams rp) {
+  uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t rank = blockIdx.x * kBlock + threadIdx.x; rank < st.n_pix; rank += stride) {
+    V3 sum = v3(0, 0, 0);
+    for (uint32_t c = 0; c < st.n_chunks; ++c) sum = sum + v3(st.partial[(size_t)c * st.n_pix + rank]);
+    V3 px = sum / (float)rp.spp;                                       // main.rs:104 / :121
+    uint32_t pixel = item_pixel(st, sc.cam, rank);
+    float* o = st.film + (size_t)pixel * 3;
+    o[0] = px.x; o[1] = px.y; o[2] = px.z;
+  }
+}
+
+// ---- diagnostics kernels (lr_selftest_*) ----------------------------------------------------------
+__global__ void k_selftest_math(int fn, const float* a, const float* b, float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f, s, c;
+  switch (fn) {
+    case 0: det_sincos(x, &s, &c); r = s; break;
+    case 1: det_sincos(x, &s, &c); r = c; break;
+    case 2: r = det_acos(x); break;
+    case 3: r = det_atan2(x, y); break;
+    case 4: r = det_pow(x, y); break;
+    case 5: r = det_exp(x); break;
+    case 6: r = det_fmod_pos(x, y); break;
+    case 7: r = x / y; break;
+    case 8: r = __builtin_sqrtf(x); break;
+    case 9: r = checker(x, y); break;
+  }
+  out[i] = r;
+}
+__global__ void k_selftest_rng(uint32_t seed, const uint32_t* pixel, const uint32_t* sample, const uint32_t* block, float* out4, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Draw4 d = rng_block(seed, pixel[i], sample[i], block[i]);
+  out4[4 * i] = d.v[0]; out4[4 * i + 1] = d.v[1]; out4[4 * i + 2] = d.v[2]; out4[4 * i + 3] = d.v[3];
+}
+__global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, int stack_depth, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* stk_n = lds;
+  float* stk_t = (float*)(lds + (size_t)stack_depth * kBlock);
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+  TraceResult r = traverse<false>(sc, o, d, 0.0f, stk_n, stk_t);
+  prim_out[i] = r.prim; t_out[i] = r.prim >= 0 ? r.t : 0.0f;
+}
+
+}  // namespace lr

@@ -1,0 +1,229 @@
+// lr_math.h -- device math for the gfx950 kernels.
+//
+// Everything that decides a discrete outcome (hit / miss, which primitive, RR survive, which
+// texel) must round exactly like the reference's f32 arithmetic: IEEE + - * / sqrt with NO fused
+// multiply-add.  This translation unit is compiled with -ffp-contract=off; only the conservative
+// box test (lr_trace.h) re-enables contraction locally.  Transcendentals follow DESIGN.md
+// "deterministic math spec": fixed polynomial forms shared with the parity oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LR_DEV __device__ __forceinline__
+
+namespace lr {
+
+constexpr float kPi  = 3.14159265358979323846264338327950288f;   // constant.rs:1
+constexpr float kEps = 1e-3f;                                     // constant.rs:2
+constexpr float kInf = 1e5f;                                      // constant.rs:3
+
+struct V3 { float x, y, z; };
+LR_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+LR_DEV V3 v3(float4 a) { return v3(a.x, a.y, a.z); }
+LR_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+LR_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LR_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LR_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+LR_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+LR_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+LR_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+LR_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // vector3.rs:77-81
+LR_DEV V3 cross(V3 a, V3 b) {                                                         // vector3.rs:83-91
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+LR_DEV float sqr_norm(V3 a) { return dot(a, a); }
+LR_DEV float norm(V3 a) { return __builtin_sqrtf(sqr_norm(a)); }
+LR_DEV V3 normalize(V3 a) { return a / norm(a); }
+LR_DEV float fmax_rs(float a, float b) { return __builtin_fmaxf(a, b); }
+LR_DEV float fmin_rs(float a, float b) { return __builtin_fminf(a, b); }
+
+// ---- sin / cos (Cephes single-precision forms, both from one reduction) --------------------
+LR_DEV void det_sincos(float xx, float* s_out, float* c_out) {
+  const float FOPI = 1.27323954473516f;
+  const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+  float x = __builtin_fabsf(xx);
+  int j = (int)(FOPI * x);
+  float y = (float)j;
+  if (j & 1) { j += 1; y += 1.0f; }
+  j &= 7;
+  bool sneg = xx < 0.0f, cneg = false;
+  if (j > 3) { sneg = !sneg; cneg = !cneg; j -= 4; }
+  if (j > 1) cneg = !cneg;
+  x = ((x - y * DP1) - y * DP2) - y * DP3;
+  float z = x * x;
+  float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z;
+  pc = pc - 0.5f * z;
+  pc = pc + 1.0f;
+  float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x;
+  ps = ps + x;
+  bool swap = (j == 1 || j == 2);
+  float s = swap ? pc : ps, c = swap ? ps : pc;
+  *s_out = sneg ? -s : s;
+  *c_out = cneg ? -c : c;
+}
+
+LR_DEV float det_atan(float xx) {
+  const float PIO2F = 1.5707963267948966192f, PIO4F = 0.7853981633974483096f;
+  float x = __builtin_fabsf(xx), y;
+  if (x > 2.414213562373095f) { y = PIO2F; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = PIO4F; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  float z = x * x;
+  float p = (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
+  y = y + p;
+  return xx < 0.0f ? -y : y;
+}
+LR_DEV float det_atan2(float y, float x) {
+  const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
+  if (x != x || y != y) return __builtin_nanf("");
+  int code = 0;
+  if (x < 0.0f) code = 2;
+  if (y < 0.0f) code |= 1;
+  if (x == 0.0f) {
+    if (code & 1) return -PIO2F;
+    if (y == 0.0f) return 0.0f;
+    return PIO2F;
+  }
+  if (y == 0.0f) return (code & 2) ? PIF : 0.0f;
+  float w = (code == 2) ? PIF : (code == 3 ? -PIF : 0.0f);
+  return w + det_atan(y / x);
+}
+LR_DEV float det_asin(float xx) {
+  const float PIO2F = 1.5707963267948966192f;
+  float a = __builtin_fabsf(xx);
+  if (a > 1.0f || a != a) return __builtin_nanf("");
+  if (a < 1.0e-4f) return xx;
+  float x, z; bool flag;
+  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = __builtin_sqrtf(z); flag = true; }
+  else { x = a; z = x * x; flag = false; }
+  z = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z + 7.4953002686E-2f) * z + 1.6666752422E-1f) * z * x + x;
+  if (flag) { z = z + z; z = PIO2F - z; }
+  return xx < 0.0f ? -z : z;
+}
+LR_DEV float det_acos(float x) {
+  const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
+  if (x != x || x < -1.0f || x > 1.0f) return __builtin_nanf("");
+  if (x < -0.5f) return PIF - 2.0f * det_asin(__builtin_sqrtf(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * det_asin(__builtin_sqrtf(0.5f * (1.0f - x)));
+  return PIO2F - det_asin(x);
+}
+
+// ---- pow / exp through f64 series (rare: Phong / Blinn-Phong lobes, Beer absorption) --------
+LR_DEV double det_log2_d(double x) {
+  uint64_t b = (uint64_t)__double_as_longlong(x);
+  int e = (int)((b >> 52) & 0x7ff);
+  if (e == 0) { x = x * 18014398509481984.0; b = (uint64_t)__double_as_longlong(x); e = (int)((b >> 52) & 0x7ff) - 54; }
+  e -= 1023;
+  b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  double m = __longlong_as_double((long long)b);
+  if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+  double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+  double p = 0.043478260869565216;
+  p = p * s2 + 0.047619047619047616;
+  p = p * s2 + 0.052631578947368418;
+  p = p * s2 + 0.058823529411764705;
+  p = p * s2 + 0.066666666666666666;
+  p = p * s2 + 0.076923076923076927;
+  p = p * s2 + 0.090909090909090912;
+  p = p * s2 + 0.1111111111111111;
+  p = p * s2 + 0.14285714285714285;
+  p = p * s2 + 0.2;
+  p = p * s2 + 0.33333333333333331;
+  p = p * s2 + 1.0;
+  double ln_m = 2.0 * s * p;
+  return (double)e + ln_m * 1.4426950408889634;
+}
+LR_DEV double det_exp2_d(double z) {
+  if (z != z) return z;
+  if (z > 1025.0) return __longlong_as_double(0x7ff0000000000000LL);
+  if (z < -1100.0) return 0.0;
+  double n = __builtin_floor(z + 0.5);
+  double t = (z - n) * 0.69314718055994529;
+  double p = 1.6059043836821613e-10;
+  p = p * t + 2.08767569878681e-09;
+  p = p * t + 2.505210838544172e-08;
+  p = p * t + 2.7557319223985888e-07;
+  p = p * t + 2.7557319223985893e-06;
+  p = p * t + 2.4801587301587302e-05;
+  p = p * t + 0.00019841269841269841;
+  p = p * t + 0.0013888888888888889;
+  p = p * t + 0.0083333333333333332;
+  p = p * t + 0.041666666666666664;
+  p = p * t + 0.16666666666666666;
+  p = p * t + 0.5;
+  p = p * t + 1.0;
+  p = p * t + 1.0;
+  int ni = (int)n;
+  int n1 = ni / 2, n2 = ni - n1;
+  double s1 = __longlong_as_double((long long)((uint64_t)(n1 + 1023) << 52));
+  double s2 = __longlong_as_double((long long)((uint64_t)(n2 + 1023) << 52));
+  return p * s1 * s2;
+}
+LR_DEV float det_pow(float x, float y) {
+  const float FINF = __builtin_huge_valf();
+  if (y == 0.0f) return 1.0f;
+  if (x != x || y != y) return __builtin_nanf("");
+  if (x == 1.0f) return 1.0f;
+  bool y_int = __builtin_floorf(y) == y;
+  bool y_odd = y_int && __builtin_fabsf(y) < 16777216.0f && (((long long)__builtin_fabsf(y)) & 1);
+  bool xneg = (__float_as_uint(x) >> 31) != 0;
+  if (x == 0.0f) {
+    if (y > 0.0f) return (y_odd && xneg) ? -0.0f : 0.0f;
+    return (y_odd && xneg) ? -FINF : FINF;
+  }
+  float ax = __builtin_fabsf(x);
+  if (ax == FINF) {
+    float r = y > 0.0f ? FINF : 0.0f;
+    return (x < 0.0f && y_odd) ? -r : r;
+  }
+  if (__builtin_fabsf(y) == FINF) {
+    if (ax == 1.0f) return 1.0f;
+    return ((ax > 1.0f) == (y > 0.0f)) ? FINF : 0.0f;
+  }
+  if (x < 0.0f && !y_int) return __builtin_nanf("");
+  float r = (float)det_exp2_d((double)y * det_log2_d((double)ax));
+  return (x < 0.0f && y_odd) ? -r : r;
+}
+LR_DEV float det_exp(float x) {
+  if (x != x) return x;
+  return (float)det_exp2_d((double)x * 1.4426950408889634);
+}
+// exact f32 remainder for x >= 0, k > 0 (Rust `%`)
+LR_DEV float det_fmod_pos(float x, float k) {
+  if (!(x < 3.0e7f)) return __builtin_fmodf(x, k);
+  float q = __builtin_floorf(x / k);
+  float r = x - q * k;
+  if (r < 0.0f) r = r + k;
+  if (r >= k) r = r - k;
+  return r;
+}
+LR_DEV float det_powi(float a, int b) {           // compiler-rt __powisf2
+  bool recip = b < 0;
+  float r = 1.0f;
+  while (true) {
+    if (b & 1) r = r * a;
+    b /= 2;
+    if (b == 0) break;
+    a = a * a;
+  }
+  return recip ? 1.0f / r : r;
+}
+
+// ---- counter-based RNG: pcg4d over (pixel, sample, block, seed) ------------------------------
+struct Draw4 { float v[4]; };
+LR_DEV Draw4 rng_block(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t block) {
+  uint32_t x = pixel, y = sample, z = block, w = seed;
+  x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u;
+  z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
+  x += y * w; y += z * x; z += x * y; w += y * z;
+  x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+  x += y * w; y += z * x; z += x * y; w += y * z;
+  Draw4 d;
+  d.v[0] = (float)(x >> 8) * 5.9604644775390625e-08f;
+  d.v[1] = (float)(y >> 8) * 5.9604644775390625e-08f;
+  d.v[2] = (float)(z >> 8) * 5.9604644775390625e-08f;
+  d.v[3] = (float)(w >> 8) * 5.9604644775390625e-08f;
+  return d;
+}
+
+}  // namespace lr

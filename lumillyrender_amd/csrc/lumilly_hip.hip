@@ -1,0 +1,531 @@
+// lumilly_hip.hip -- C ABI of liblumilly_hip.so (include/lumilly_hip.h): scene upload, the
+// wavefront render loop and its measurement hooks.  gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).  The -ffp-contract
+// flag is part of the contract with the parity oracle: hit/miss decisions must round like the
+// reference's f32 code.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lumilly_hip.h"
+#include "lr_kernels.h"
+
+using namespace lr;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct ApiError { int code; std::string msg; };
+[[noreturn]] void fail(int code, const std::string& m) { throw ApiError{code, m}; }
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) fail(LR_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_OK(x) hip_check((x), #x)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  void ensure(size_t count) {
+    if (count <= n && p) return;
+    release();
+    HIP_OK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    n = std::max<size_t>(count, 1);
+  }
+  void upload(const std::vector<T>& v, hipStream_t s) {
+    ensure(v.size());
+    if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+};
+
+constexpr int kEventPool = 1024;      // timed launches per kernel type per render
+constexpr int kProfileStride = 2;     // time every 2nd iteration when LR_FLAG_PROFILE is set
+
+struct EventPool {
+  std::vector<hipEvent_t> a, b; int used = 0;
+  void init() {
+    if (!a.empty()) return;
+    a.resize(kEventPool); b.resize(kEventPool);
+    for (int i = 0; i < kEventPool; ++i) { HIP_OK(hipEventCreate(&a[i])); HIP_OK(hipEventCreate(&b[i])); }
+  }
+  void destroy() { for (auto e : a) (void)hipEventDestroy(e); for (auto e : b) (void)hipEventDestroy(e); a.clear(); b.clear(); }
+};
+
+}  // namespace
+
+struct LrScene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cus = 0;
+  // scene blob
+  DevBuf<float4> nodes, prims, shade, mats, emit, texels;
+  DevBuf<uint8_t> prim_qid;
+  DevScene dev;
+  bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
+  int stack_depth = 2;
+  int film_w = 0, film_h = 0;
+  // render state (kept between calls)
+  DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
+  DevBuf<float2> hit;
+  DevBuf<uint32_t> queues, counters, tile_prefix;
+  DevBuf<int4> tiles;
+  DevBuf<unsigned long long> stats_dev;
+  DevBuf<float> film;
+  uint32_t* pinned = nullptr;         // [0..1] retired-slot read-backs, [2..] stats
+  hipEvent_t poll_ev[2] = {nullptr, nullptr};
+  hipEvent_t t_begin = nullptr, t_end = nullptr;
+  EventPool pools[LR_K_COUNT];
+  LrStats stats;
+  std::vector<float> host_film;
+};
+
+namespace {
+
+void pack_scene(LrScene& s, const LrSceneDesc& d) {
+  if (d.abi_version != LR_ABI_VERSION) fail(LR_EINVAL, "LrSceneDesc.abi_version mismatch");
+  if (d.n_prims < 0 || d.n_materials < 0 || (d.n_prims > 0 && (!d.prims || !d.materials))) fail(LR_EINVAL, "bad primitive / material arrays");
+  if (d.n_bvh_nodes < 1 || !d.bvh_nodes || (d.n_prims > 0 && !d.bvh_prim_order)) fail(LR_EINVAL, "missing BVH (build it with lr_host_build_bvh)");
+  if (d.camera.resolution[0] <= 0 || d.camera.resolution[1] <= 0) fail(LR_EINVAL, "bad film resolution");
+  if ((uint64_t)d.camera.resolution[0] * (uint64_t)d.camera.resolution[1] > 0xffffffffull) fail(LR_EINVAL, "film too large");
+  if (d.camera.type < 0 || d.camera.type > LR_CAMERA_OMNIDIRECTIONAL) fail(LR_EINVAL, "unknown camera type");
+  const int np = d.n_prims;
+
+  // materials (weight: lambert.rs:27-30 and the other four `weight` impls)
+  std::vector<float4> mats((size_t)d.n_materials * 3);
+  for (int i = 0; i < d.n_materials; ++i) {
+    const LrMaterial& m = d.materials[i];
+    if (m.type < 0 || m.type > LR_MAT_IDEAL_REFRACTION) fail(LR_EINVAL, "unknown material type");
+    float w = std::fmax(std::fmax(m.color[0], m.color[1]), m.color[2]);
+    bool emits = m.type == LR_MAT_LAMBERT;                        // only Lambert has emission (lambert.rs:23-25)
+    mats[3 * i] = make_float4(m.color[0], m.color[1], m.color[2], __builtin_bit_cast(float, (uint32_t)m.type));
+    mats[3 * i + 1] = make_float4(emits ? m.emission[0] : 0.0f, emits ? m.emission[1] : 0.0f, emits ? m.emission[2] : 0.0f, w);
+    mats[3 * i + 2] = make_float4(m.param[0], m.param[1], m.param[2], 0.0f);
+    s.mat_present[m.type] = s.mat_present[m.type];               // presence is decided per primitive below
+  }
+
+  // per-primitive shading rows + emitter table (objects.rs:19-24) in instance order
+  std::vector<float4> shade((size_t)np), emit;
+  std::vector<uint8_t> qid((size_t)np);
+  std::vector<float> area((size_t)np);
+  for (int q = 0; q < kNumShadeQueues - 1; ++q) s.mat_present[q] = false;
+  for (int i = 0; i < np; ++i) {
+    const LrPrimitive& p = d.prims[i];
+    if (p.material < 0 || p.material >= d.n_materials) fail(LR_EINVAL, "primitive material index out of range");
+    uint32_t mw = (uint32_t)p.material;
+    if (p.type == LR_PRIM_TRIANGLE) {                            // triangle.rs:25-40
+      float e1[3] = {p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2]};
+      float e2[3] = {p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2]};
+      float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      shade[i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
+      area[i] = nrm * 0.5f;
+    } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
+      shade[i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
+      area[i] = 4.0f * kPi * (p.v[3] * p.v[3]);
+    } else fail(LR_EINVAL, "unknown primitive type");
+    int mt = d.materials[p.material].type;
+    qid[i] = (uint8_t)mt;
+    s.mat_present[mt] = true;
+  }
+  float emission_area = 0.0f;
+  std::vector<int> emitters;
+  for (int i = 0; i < np; ++i) {
+    const LrMaterial& m = d.materials[d.prims[i].material];
+    if (m.type != LR_MAT_LAMBERT) continue;
+    float e2 = m.emission[0] * m.emission[0] + m.emission[1] * m.emission[1] + m.emission[2] * m.emission[2];
+    if (e2 > 0.0f) emitters.push_back(i);
+  }
+  for (int i : emitters) emission_area += area[i];               // objects.rs:24 (.sum() in instance order)
+  {
+    float cum = 0.0f;
+    for (int i : emitters) {
+      const LrPrimitive& p = d.prims[i];
+      cum += area[i];                                            // objects.rs:41
+      float pdf = (1.0f / area[i]) * area[i] / emission_area;    // objects.rs:46 with triangle.rs:147 / sphere.rs:82
+      if (p.type == LR_PRIM_TRIANGLE) {
+        emit.push_back(make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)LR_PRIM_TRIANGLE)));
+        emit.push_back(make_float4(p.v[3], p.v[4], p.v[5], pdf));
+        emit.push_back(make_float4(p.v[6], p.v[7], p.v[8], cum));
+      } else {
+        emit.push_back(make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)LR_PRIM_SPHERE)));
+        emit.push_back(make_float4(p.v[3], 0.0f, 0.0f, pdf));
+        emit.push_back(make_float4(0.0f, 0.0f, 0.0f, cum));
+      }
+    }
+  }
+
+  // BVH nodes + primitives in leaf order
+  std::vector<float4> nodes((size_t)d.n_bvh_nodes * 4), prims((size_t)std::max(np, 1) * 3);
+  std::vector<char> seen((size_t)np, 0);
+  for (int i = 0; i < d.n_bvh_nodes; ++i) {
+    const LrBvhNode& n = d.bvh_nodes[i];
+    nodes[4 * i] = make_float4(n.x[0], n.x[1], n.x[2], n.x[3]);
+    nodes[4 * i + 1] = make_float4(n.y[0], n.y[1], n.y[2], n.y[3]);
+    nodes[4 * i + 2] = make_float4(n.z[0], n.z[1], n.z[2], n.z[3]);
+    nodes[4 * i + 3] = make_float4(__builtin_bit_cast(float, n.child[0]), __builtin_bit_cast(float, n.child[1]), 0.0f, 0.0f);
+    for (int c = 0; c < 2; ++c) {
+      int ch = n.child[c];
+      if (ch >= 0) { if (ch >= d.n_bvh_nodes || ch <= i) fail(LR_EINVAL, "BVH child index out of order"); continue; }
+      uint32_t enc = (uint32_t)~ch, first = enc >> 3, count = enc & 7u;
+      if ((uint64_t)first + count > (uint64_t)np) fail(LR_EINVAL, "BVH leaf range out of bounds");
+      for (uint32_t k = first; k < first + count; ++k) {
+        int id = d.bvh_prim_order[k];
+        if (id < 0 || id >= np || seen[id]) fail(LR_EINVAL, "BVH primitive order is not a permutation");
+        seen[id] = 1;
+        const LrPrimitive& p = d.prims[id];
+        if (p.type == LR_PRIM_TRIANGLE) {                        // e1, e2 of triangle.rs:71-72
+          prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
+          prims[3 * k + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
+          prims[3 * k + 2] = make_float4(p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2], 0.0f);
+        } else {
+          prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id | 0x80000000u));
+          prims[3 * k + 1] = make_float4(p.v[3], p.v[3] * p.v[3], 0.0f, 0.0f);
+          prims[3 * k + 2] = make_float4(0, 0, 0, 0);
+        }
+      }
+    }
+  }
+  for (int i = 0; i < np; ++i) if (!seen[i]) fail(LR_EINVAL, "BVH does not reference every primitive");
+  if (d.bvh_max_depth < 1 || d.bvh_max_depth > 96) fail(LR_EINVAL, "bvh_max_depth out of range (1..96)");
+  s.stack_depth = d.bvh_max_depth + 1;
+
+  std::vector<float4> texels;
+  if (d.sky.type == LR_SKY_IBL) {
+    if (d.sky.height <= 0 || !d.sky.texels) fail(LR_EINVAL, "IBL sky without texels");
+    size_t n = (size_t)d.sky.height * (size_t)d.sky.height * 2;
+    texels.resize(n);
+    for (size_t i = 0; i < n; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
+  } else if (d.sky.type != LR_SKY_UNIFORM) fail(LR_EINVAL, "unknown sky type");
+
+  s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); s.shade.upload(shade, s.stream);
+  s.mats.upload(mats, s.stream); s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
+  s.prim_qid.upload(qid, s.stream);
+  HIP_OK(hipStreamSynchronize(s.stream));
+
+  DevScene& v = s.dev;
+  std::memset(&v, 0, sizeof(v));
+  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.mats = s.mats.p; v.emit = s.emit.p;
+  v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
+  v.n_emitters = (int)emitters.size(); v.emission_area = emission_area;
+  v.sky_type = d.sky.type; v.sky_color[0] = d.sky.color[0]; v.sky_color[1] = d.sky.color[1]; v.sky_color[2] = d.sky.color[2];
+  v.sky_h = d.sky.height; v.sky_lon = d.sky.longitude_offset;
+  const LrCamera& c = d.camera;
+  DevCamera& dc = v.cam;
+  dc.type = c.type; dc.res_w = c.resolution[0]; dc.res_h = c.resolution[1];
+  for (int k = 0; k < 3; ++k) { dc.forward[k] = c.forward[k]; dc.right[k] = c.right[k]; dc.up[k] = c.up[k]; dc.position[k] = c.position[k]; dc.aperture_position[k] = c.aperture_position[k]; }
+  dc.sensor_w = c.sensor_size[0]; dc.sensor_h = c.sensor_size[1];
+  dc.aperture_sensor_distance = c.aperture_sensor_distance; dc.aperture_radius = c.aperture_radius;
+  dc.focus_distance = c.focus_distance; dc.sensor_pixel_area = c.sensor_pixel_area;
+  dc.weight2 = 1.0f;
+  if (c.type == LR_CAMERA_THIN_LENS) {                           // camera.rs:426,438 pdfs; main.rs:118 sens / pdf
+    float sensor_pdf = 1.0f / c.sensor_pixel_area;
+    float aperture_pdf = 1.0f / (kPi * c.aperture_radius * c.aperture_radius);
+    dc.weight2 = c.sensor_sensitivity / (sensor_pdf * aperture_pdf);
+  }
+  s.film_w = c.resolution[0]; s.film_h = c.resolution[1];
+}
+
+int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 8);
+  long long want = ((long long)work_items + kBlock - 1) / kBlock;
+  long long cap = (long long)n_cus * per_cu;
+  return (int)std::max<long long>(1, std::min(want, cap));
+}
+
+struct Launcher {
+  LrScene& s; bool profile; int iter = 0;
+  bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
+  template <class F> void run(int k, F&& launch) {
+    bool t = timed(k);
+    EventPool& p = s.pools[k];
+    if (t) HIP_OK(hipEventRecord(p.a[p.used], s.stream));
+    launch();
+    HIP_OK(hipGetLastError());
+    if (t) { HIP_OK(hipEventRecord(p.b[p.used], s.stream)); p.used++; }
+    s.stats.kernel_launches[k]++;
+  }
+};
+
+void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, int n_tiles) {
+  if (rp_in.spp <= 0) fail(LR_EINVAL, "spp must be positive");
+  if (rp_in.integrator != LR_INTEGRATOR_PT && rp_in.integrator != LR_INTEGRATOR_PT_DIRECT) fail(LR_EINVAL, "unknown integrator");
+  if (rp_in.depth < 0 || rp_in.depth_limit < 0) fail(LR_EINVAL, "negative depth");
+  if (n_tiles < 0 || (n_tiles > 0 && !tiles)) fail(LR_EINVAL, "bad tile list");
+  HIP_OK(hipSetDevice(s.device));
+  const int W = s.film_w, H = s.film_h;
+  // tile list -> prefix of pixel ranks
+  std::vector<int4> tl; std::vector<uint32_t> prefix; uint64_t npix64 = 0;
+  for (int i = 0; i < n_tiles; ++i) {
+    const LrTile& t = tiles[i];
+    if (t.w < 0 || t.h < 0 || t.x0 < 0 || t.y0 < 0 || (long long)t.x0 + t.w > W || (long long)t.y0 + t.h > H) fail(LR_EINVAL, "tile outside the film");
+    if (t.w == 0 || t.h == 0) continue;
+    tl.push_back(make_int4(t.x0, t.y0, t.w, t.h)); prefix.push_back((uint32_t)npix64);
+    npix64 += (uint64_t)t.w * (uint64_t)t.h;
+  }
+  prefix.push_back((uint32_t)npix64);
+  if (npix64 > (uint64_t)W * (uint64_t)H) fail(LR_EINVAL, "tiles overlap (more tile pixels than film pixels)");
+  const uint32_t n_pix = (uint32_t)npix64;
+  // chunks: a function of spp ONLY, so the image does not depend on tiling, slot count or GPU count
+  uint32_t n_chunks = (uint32_t)std::min(64, std::max(1, rp_in.spp / 8));
+  uint32_t chunk_spp = ((uint32_t)rp_in.spp + n_chunks - 1) / n_chunks;
+  n_chunks = ((uint32_t)rp_in.spp + chunk_spp - 1) / chunk_spp;
+  uint64_t n_items64 = (uint64_t)n_pix * n_chunks;
+  if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
+  const uint32_t n_items = (uint32_t)n_items64;
+  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (1u << 20);
+  n_slots = std::max<uint32_t>(kBlock, std::min<uint32_t>(n_slots, ((n_items + kBlock - 1) / kBlock) * kBlock));
+  n_slots = (n_slots + kBlock - 1) / kBlock * kBlock;
+
+  hipStream_t st = s.stream;
+  s.ray_o.ensure(n_slots); s.ray_d.ensure(n_slots); s.hit.ensure(n_slots); s.thr.ensure(n_slots); s.rad.ensure(n_slots);
+  s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
+  s.queues.ensure((size_t)(kNumShadeQueues + 1) * n_slots);
+  s.counters.ensure(2 * kCountersPerParity + 2);
+  s.stats_dev.ensure(ST_COUNT + 2);
+  s.partial.ensure(n_items);
+  s.film.ensure((size_t)W * H * 3);
+  s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st);
+  if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, 64 * sizeof(uint64_t)));
+  if (!s.poll_ev[0]) { HIP_OK(hipEventCreate(&s.poll_ev[0])); HIP_OK(hipEventCreate(&s.poll_ev[1])); HIP_OK(hipEventCreate(&s.t_begin)); HIP_OK(hipEventCreate(&s.t_end)); }
+  const bool profile = (rp_in.flags & LR_FLAG_PROFILE) != 0, count = (rp_in.flags & LR_FLAG_COUNT) != 0;
+  if (profile) for (auto& p : s.pools) p.init();
+  for (auto& p : s.pools) p.used = 0;
+
+  DevState ds; std::memset(&ds, 0, sizeof(ds));
+  ds.ray_o = s.ray_o.p; ds.ray_d = s.ray_d.p; ds.hit = s.hit.p; ds.thr = s.thr.p; ds.rad = s.rad.p; ds.acc = s.acc.p;
+  ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p; ds.queues = s.queues.p; ds.counters = s.counters.p;
+  ds.next_item = s.counters.p + 2 * kCountersPerParity; ds.n_retired = ds.next_item + 1;
+  ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p;
+  ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size();
+  ds.n_slots = n_slots; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
+  ds.stack_depth = s.stack_depth;
+  DevParams dp; dp.integrator = rp_in.integrator; dp.spp = rp_in.spp; dp.seed = rp_in.seed; dp.depth = rp_in.depth;
+  dp.depth_limit = rp_in.depth_limit; dp.no_direct_emitter = rp_in.no_direct_emitter ? 1 : 0;
+
+  LrStats& S = s.stats;
+  double keep_upload = S.upload_ms;
+  std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload;
+
+  HIP_OK(hipMemsetAsync(s.counters.p, 0, (2 * kCountersPerParity + 2) * sizeof(uint32_t), st));
+  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, (ST_COUNT + 2) * sizeof(unsigned long long), st));
+  HIP_OK(hipEventRecord(s.t_begin, st));
+
+  const size_t lds = (size_t)s.stack_depth * kBlock * 8;
+  const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
+  const void* kshadow = count ? (const void*)k_shadow<true> : (const void*)k_shadow<false>;
+  const int g_trace = grid_for(ktrace, s.n_cus, lds, n_slots);
+  const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_slots);
+  const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_slots);
+  int g_shade[kNumShadeQueues];
+  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_slots);
+  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_slots);
+  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_slots);
+  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_slots);
+  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_slots);
+  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_slots);
+
+  Launcher L{s, profile};
+  if (n_items > 0) {
+    L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, s.dev, ds, dp); });
+    const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
+    const int kCheck = 8;
+    int parity = 0, batch = 0;
+    bool done = false;
+    // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
+    // length statistically, this bounds the loop against a logic error
+    const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
+    while (!done) {
+      for (int k = 0; k < kCheck; ++k) {
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, parity); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, parity); });
+        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (nee) {
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, parity); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, parity); });
+        }
+        parity ^= 1; L.iter++; S.iterations++;
+      }
+      // poll the retired-slot counter one batch behind so the queue never drains
+      HIP_OK(hipMemcpyAsync(&s.pinned[batch & 1], ds.n_retired, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipEventRecord(s.poll_ev[batch & 1], st));
+      if (batch > 0) {
+        HIP_OK(hipEventSynchronize(s.poll_ev[(batch - 1) & 1]));
+        if (s.pinned[(batch - 1) & 1] >= n_slots) done = true;
+      }
+      ++batch;
+      if (S.iterations > max_iter) fail(LR_EDEVICE, "render loop did not terminate (internal error)");
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    if (s.pinned[(batch - 1) & 1] < n_slots) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
+  }
+  if (n_pix > 0) {
+    int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, n_pix);
+    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, s.dev, ds, dp); });
+  }
+  HIP_OK(hipEventRecord(s.t_end, st));
+  unsigned long long* hstats = (unsigned long long*)(s.pinned + 8);
+  HIP_OK(hipMemcpyAsync(hstats, s.stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  float ms = 0.0f; HIP_OK(hipEventElapsedTime(&ms, s.t_begin, s.t_end));
+  S.render_ms = ms;
+  S.samples = hstats[ST_SAMPLES]; S.segments = hstats[ST_SEGMENTS]; S.shadow_rays = hstats[ST_SHADOW];
+  S.node_visits = hstats[ST_NODE_VISITS]; S.prim_tests = hstats[ST_PRIM_TESTS]; S.sky_fetches = hstats[ST_SKY];
+  for (int k = 0; k < LR_K_COUNT; ++k) {
+    EventPool& p = s.pools[k];
+    for (int i = 0; i < p.used; ++i) { float e = 0.0f; HIP_OK(hipEventElapsedTime(&e, p.a[i], p.b[i])); S.kernel_ms[k] += e; }
+    S.kernel_timed[k] = (uint64_t)p.used;
+  }
+}
+
+}  // namespace
+
+#define LR_TRY(...)                                                                     \
+  try { __VA_ARGS__; return LR_OK; }                                                    \
+  catch (const ApiError& e) { g_err = e.msg; return e.code; }                           \
+  catch (const std::bad_alloc&) { g_err = "out of host memory"; return LR_ENOMEM; }     \
+  catch (const std::exception& e) { g_err = e.what(); return LR_EINVAL; }
+
+extern "C" {
+
+const char* lr_last_error(void) { return g_err.c_str(); }
+const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=1"; }
+
+int lr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { g_err = "hipGetDeviceCount failed"; return 0; }
+  return n;
+}
+
+int lr_scene_create(int device, const LrSceneDesc* desc, LrScene** out) {
+  LrScene* s = nullptr;
+  try {
+    if (!desc || !out) fail(LR_EINVAL, "null argument");
+    int n = 0; HIP_OK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) fail(LR_EINVAL, "no such device");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_OK(hipSetDevice(device));
+    s = new LrScene();
+    s->device = device;
+    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device));
+    s->n_cus = prop.multiProcessorCount;
+    HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    std::memset(&s->stats, 0, sizeof(s->stats));
+    pack_scene(*s, *desc);
+    s->stats.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = s;
+    return LR_OK;
+  } catch (const ApiError& e) { g_err = e.msg; if (s) lr_scene_destroy(s); return e.code; }
+  catch (const std::bad_alloc&) { g_err = "out of host memory"; if (s) lr_scene_destroy(s); return LR_ENOMEM; }
+}
+
+int lr_scene_destroy(LrScene* s) {
+  if (!s) return LR_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  s->nodes.release(); s->prims.release(); s->shade.release(); s->mats.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
+  s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
+  s->partial.release(); s->hit.release(); s->queues.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release();
+  s->stats_dev.release(); s->film.release();
+  if (s->pinned) (void)hipHostFree(s->pinned);
+  for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
+  if (s->t_begin) (void)hipEventDestroy(s->t_begin);
+  if (s->t_end) (void)hipEventDestroy(s->t_end);
+  for (auto& p : s->pools) p.destroy();
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return LR_OK;
+}
+
+int lr_render_device(LrScene* s, const LrRenderParams* params, const LrTile* tiles, int n_tiles, void** film_dev) {
+  LR_TRY({
+    if (!s || !params) fail(LR_EINVAL, "null argument");
+    render_impl(*s, *params, tiles, n_tiles);
+    if (film_dev) *film_dev = s->film.p;
+  })
+}
+
+int lr_render(LrScene* s, const LrRenderParams* params, const LrTile* tiles, int n_tiles, float* rgb_out, size_t row_stride_floats) {
+  LR_TRY({
+    if (!s || !params || !rgb_out) fail(LR_EINVAL, "null argument");
+    if (row_stride_floats < (size_t)s->film_w * 3) fail(LR_EINVAL, "row stride smaller than one film row");
+    render_impl(*s, *params, tiles, n_tiles);
+    const int W = s->film_w, H = s->film_h;
+    s->host_film.resize((size_t)W * H * 3);
+    HIP_OK(hipMemcpyAsync(s->host_film.data(), s->film.p, s->host_film.size() * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n_tiles; ++i) {                            // only tile pixels are written (Img::set per job, main.rs:129-132)
+      const LrTile& t = tiles[i];
+      for (int y = t.y0; y < t.y0 + t.h; ++y)
+        std::memcpy(rgb_out + (size_t)y * row_stride_floats + (size_t)t.x0 * 3, s->host_film.data() + ((size_t)y * W + t.x0) * 3, (size_t)t.w * 3 * sizeof(float));
+    }
+  })
+}
+
+int lr_get_stats(LrScene* s, LrStats* out) {
+  if (!s || !out) { g_err = "null argument"; return LR_EINVAL; }
+  *out = s->stats;
+  return LR_OK;
+}
+
+// ---- diagnostics: run the device math / RNG / traversal on caller data (parity tests) -------------
+int lr_selftest_math(int device, int fn, const float* a, const float* b, float* out, int n) {
+  LR_TRY({
+    if (!a || !out || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(device));
+    DevBuf<float> da, db, dout;
+    da.ensure(n); db.ensure(n); dout.ensure(n);
+    HIP_OK(hipMemcpy(da.p, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (b) HIP_OK(hipMemcpy(db.p, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, 0, fn, da.p, b ? db.p : (const float*)nullptr, dout.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    da.release(); db.release(); dout.release();
+  })
+}
+int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint32_t* sample, const uint32_t* block, float* out4, int n) {
+  LR_TRY({
+    if (!pixel || !sample || !block || !out4 || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(device));
+    DevBuf<uint32_t> dp, dsm, dbk; DevBuf<float> dout;
+    dp.ensure(n); dsm.ensure(n); dbk.ensure(n); dout.ensure((size_t)n * 4);
+    HIP_OK(hipMemcpy(dp.p, pixel, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dsm.p, sample, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dbk.p, block, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_rng, dim3((n + 255) / 256), dim3(256), 0, 0, seed, dp.p, dsm.p, dbk.p, dout.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out4, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    dp.release(); dsm.release(); dbk.release(); dout.release();
+  })
+}
+int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
+  LR_TRY({
+    if (!s || !origins || !dirs || !prim_out || !t_out || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<float> dor, ddr, dt; DevBuf<int> dpr;
+    dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
+    HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    size_t lds = (size_t)s->stack_depth * kBlock * 8;
+    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    dor.release(); ddr.release(); dt.release(); dpr.release();
+  })
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""ctypes binding of liblumilly_hip.so (include/lumilly_hip.h): the HIP render path.
+
+There is NO fallback: if the extension is missing or no GPU is visible, construction raises.
+Counterpart of the reference's `Scene` as the render loop sees it (scene.rs:20,34 behind
+main.rs:70-132): `Scene(description).render(params, tiles)` returns the film.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .host import LumillyError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblumilly_hip.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: the HIP extension was not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C lumillyrender_amd/csrc`). "
+            "There is no CPU fallback for the render path.")
+    l = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    fp = C.POINTER(C.c_float)
+    l.lr_last_error.restype = C.c_char_p
+    l.lr_build_info.restype = C.c_char_p
+    l.lr_device_count.restype = C.c_int
+    l.lr_scene_create.argtypes = [C.c_int, C.POINTER(abi.LrSceneDesc), C.POINTER(vp)]
+    l.lr_scene_destroy.argtypes = [vp]
+    l.lr_render.argtypes = [vp, C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int, fp, C.c_size_t]
+    l.lr_render_device.argtypes = [vp, C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int, C.POINTER(vp)]
+    l.lr_get_stats.argtypes = [vp, C.POINTER(abi.LrStats)]
+    l.lr_selftest_math.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_int]
+    up = C.POINTER(C.c_uint32)
+    l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
+    l.lr_selftest_intersect.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    _lib = l
+    return l
+
+
+def _check(rc):
+    if rc < 0:
+        raise LumillyError(rc, lib().lr_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def device_count():
+    return lib().lr_device_count()
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Scene:
+    """Device-resident scene (BVH, primitives, materials, emitters, sky) on one GPU."""
+
+    def __init__(self, description, device=0):
+        self._h = C.c_void_p()
+        self.description = description            # keeps the host arrays alive during create
+        if device_count() <= 0:
+            raise RuntimeError("lumilly_hip: no HIP device visible (the render path has no CPU fallback)")
+        _check(lib().lr_scene_create(device, description.desc_ptr, C.byref(self._h)))
+        d = description.desc
+        self.width, self.height = int(d.camera.resolution[0]), int(d.camera.resolution[1])
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().lr_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, params, tiles=None, n_tiles=None, out=None):
+        """Render `tiles` (default: the whole film) into an (H, W, 3) f32 array."""
+        if tiles is None:
+            tiles = (abi.LrTile * 1)()
+            tiles[0].x0, tiles[0].y0, tiles[0].w, tiles[0].h = 0, 0, self.width, self.height
+            n_tiles = 1
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(lib().lr_render(self._h, C.byref(params), tiles, n_tiles, _fptr(out), self.width * 3))
+        return out
+
+    def render_device(self, params, tiles, n_tiles):
+        """Render and leave the film in HBM; returns the device pointer (int)."""
+        p = C.c_void_p()
+        _check(lib().lr_render_device(self._h, C.byref(params), tiles, n_tiles, C.byref(p)))
+        return p.value
+
+    def stats(self):
+        s = abi.LrStats()
+        _check(lib().lr_get_stats(self._h, C.byref(s)))
+        return s
+
+    def intersect(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = o.shape[0]
+        prim = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float32)
+        _check(lib().lr_selftest_intersect(self._h, n, _fptr(o), _fptr(d), prim.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(t)))
+        return prim, t
+
+
+def selftest_math(fn, a, b=None, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        bp = _fptr(b)
+    _check(lib().lr_selftest_math(device, fn, _fptr(a), bp, _fptr(out), a.size))
+    return out
+
+
+def selftest_rng(seed, pixel, sample, block, device=0):
+    pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+    sample = np.ascontiguousarray(sample, dtype=np.uint32)
+    block = np.ascontiguousarray(block, dtype=np.uint32)
+    out = np.empty((pixel.size, 4), dtype=np.float32)
+    up = C.POINTER(C.c_uint32)
+    _check(lib().lr_selftest_rng(device, seed, pixel.ctypes.data_as(up), sample.ctypes.data_as(up), block.ctypes.data_as(up), _fptr(out), pixel.size))
+    return out
+
+
+def stats_dict(s):
+    d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "sky_fetches", "iterations")}
+    d["render_ms"] = float(s.render_ms)
+    d["upload_ms"] = float(s.upload_ms)
+    d["kernels"] = {
+        abi.LR_KERNEL_NAMES[k]: {"launches": int(s.kernel_launches[k]), "timed": int(s.kernel_timed[k]), "ms": float(s.kernel_ms[k])}
+        for k in range(abi.LR_K_COUNT)
+    }
+    return d

@@ -152,6 +152,17 @@ BvhResult build_bvh(const LrPrimitive* prims, int n, int max_leaf, const float* 
   // f32 slab arithmetic is good to a few ulp of |bound - origin| <= scene extent; 4e-6 * extent is
   // ~20x that (see DESIGN.md "conservative boxes")
   out.pad = std::fmax(4e-6f * diag, 1e-30f);
+  // Spheres need more: sphere.rs:45 forms cod^2 - |co|^2 + r^2, whose rounding error is a few ulp of
+  // |co|^2 <= extent^2, so the test can accept rays that pass up to sqrt(r^2 + ~2e-7 extent^2) from
+  // the centre (a radius-1 sphere seen from 1e5 away "grows" by tens of units).  The box must cover
+  // every ray the primitive test can accept, so sphere boxes grow by that amount (2x margin).
+  for (int i = 0; i < n; ++i) {
+    if (prims[i].type != LR_PRIM_SPHERE) continue;
+    float r = std::fabs(prims[i].v[3]);
+    float grow = std::sqrt(r * r + 4e-7f * diag * diag) - r;
+    for (int a = 0; a < 3; ++a) { boxes[i].mn[a] -= grow; boxes[i].mx[a] += grow; }
+    all.grow(boxes[i]);
+  }
 
   LrBvhNode root; std::memset(&root, 0, sizeof(root));
   if (n == 0) {

@@ -1,0 +1,26 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CPU-side natives (host library, oracle) are cheap to (re)build; the HIP library is built by
+    # __graft_entry__.build() and travels to the GPU box as a prebuilt .so
+    for sub in ("lumillyrender_amd/host", "oracle"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, sub)], check=True)
+
+
+@pytest.fixture(scope="session")
+def root():
+    return ROOT
+
+
+def scene_path(name):
+    return os.path.join(ROOT, "scenes", name)

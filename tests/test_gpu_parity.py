@@ -1,0 +1,211 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical scene + seed.
+
+Bar (BASELINE.json north_star): per-channel L-infinity < 1e-4 on the linear f32 film.  Discrete
+decisions (hit/miss, which primitive, RR, texel) must agree exactly; the only admitted differences are
+float re-association inside radiance sums (throughput form vs the reference's recursion; per-chunk
+partial sums), a few ulp.
+"""
+import numpy as np
+import pytest
+
+from tests.conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lumillyrender_amd import device
+    assert device.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return device
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import binding
+    return binding
+
+
+def linf(a, b):
+    assert not np.isnan(a).any() and not np.isnan(b).any()
+    return float(np.max(np.abs(a - b)))
+
+
+def load(name, w, h, text_edit=None):
+    from lumillyrender_amd import host
+    if text_edit is None:
+        d = host.Description(scene_path(name))
+    else:
+        d = host.Description(text=text_edit(open(scene_path(name)).read()))
+    d.set_resolution(w, h)
+    return d
+
+
+# ---- building blocks ---------------------------------------------------------------------------------
+
+def test_device_math_bit_exact(dev, oracle):
+    rng = np.random.default_rng(1)
+    x = (rng.random(4096) * 2 * np.pi).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(0, x), oracle.math1("sin", x))
+    assert np.array_equal(dev.selftest_math(1, x), oracle.math1("cos", x))
+    u = (rng.random(4096) * 2 - 1).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(2, u), oracle.math1("acos", u))
+    a, b = (rng.random(4096) * 4 - 2).astype(np.float32), (rng.random(4096) * 4 - 2).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(3, a, b), oracle.math2("atan2", a, b))
+    base, ex = rng.random(4096).astype(np.float32), (rng.random(4096) * 60).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(4, base, ex), oracle.math2("pow", base, ex))
+    e = (rng.random(4096) * 30 - 25).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(5, e), oracle.math1("exp", e))
+    p = (rng.random(4096) * 3000).astype(np.float32)
+    for k in (150.0, 30.0, 300.0, 1.0):
+        kk = np.full_like(p, k)
+        assert np.array_equal(dev.selftest_math(6, p, kk), np.fmod(p, kk))
+    # IEEE division and sqrt on the device (the restatement relies on them)
+    num, den = (rng.standard_normal(4096) * 100).astype(np.float32), (rng.standard_normal(4096) * 3).astype(np.float32)
+    assert np.array_equal(dev.selftest_math(7, num, den), num / den)
+    assert np.array_equal(dev.selftest_math(8, p), np.sqrt(p))
+
+
+def test_device_rng_bit_exact(dev, oracle):
+    rng = np.random.default_rng(2)
+    px = rng.integers(0, 2 ** 22, 512, dtype=np.uint32)
+    sm = rng.integers(0, 8192, 512, dtype=np.uint32)
+    bk = rng.integers(0, 140, 512, dtype=np.uint32)
+    got = dev.selftest_rng(12345, px, sm, bk)
+    want = np.stack([oracle.rng_block(12345, int(a), int(b), int(c)) for a, b, c in zip(px, sm, bk)])
+    assert np.array_equal(got, want)
+    assert got.min() >= 0.0 and got.max() < 1.0
+
+
+def _random_rays(desc, n, seed):
+    rng = np.random.default_rng(seed)
+    prims = desc.dump()["prims"]
+    pts = []
+    for p in prims:
+        v = np.array(p["v"], dtype=np.float32)
+        pts.append(v[:3])
+    pts = np.array(pts)
+    lo, hi = pts.min(0) - 50, pts.max(0) + 50
+    o = (rng.random((n, 3)) * (hi - lo) + lo).astype(np.float32)
+    tgt = pts[rng.integers(0, len(pts), n)] + rng.standard_normal((n, 3)).astype(np.float32) * 60
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    # a share of axis-parallel directions (zero components -> infinities in the slab test)
+    ax = rng.integers(0, n, n // 16)
+    d[ax] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, len(ax))] * rng.choice([-1.0, 1.0], (len(ax), 1)).astype(np.float32)
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"])
+def test_closest_hit_matches_brute_force(dev, oracle, name):
+    desc = load(name, 64, 64)
+    scene = dev.Scene(desc)
+    o, d = _random_rays(desc, 20000, 3)
+    gp, gt = scene.intersect(o, d)
+    op, ot = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gt, ot)          # distances bit for bit
+    assert (gp >= 0).mean() > 0.3
+    scene.close()
+
+
+# ---- images -------------------------------------------------------------------------------------------
+
+CASES = [
+    # scene, w, h, spp, integrator (None = scene's own)
+    ("two-spheres.toml", 48, 48, 32, None),            # spheres + uniform sky, pt
+    ("cbox-spheres.toml", 40, 40, 24, 0),              # triangles + spheres, pt (emission through bounces)
+    ("cbox-spheres.toml", 40, 40, 24, 1),              # pt-direct: NEE + shadow rays
+    ("brdf-row.toml", 64, 36, 32, 1),                  # GGX + Lambert, quad light with mtl material
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,integ", CASES)
+def test_image_parity(dev, oracle, name, w, h, spp, integ):
+    desc = load(name, w, h)
+    params = desc.render_params(spp=spp, seed=11, integrator=integ)
+    scene = dev.Scene(desc)
+    img = scene.render(params)
+    ref, ost = oracle.render(desc, params, with_stats=True)
+    st = scene.stats()
+    # identical RNG streams => identical path statistics, an exact check of every discrete decision
+    assert st.samples == w * h * spp == ost.samples
+    assert st.segments == ost.segments
+    assert st.shadow_rays == ost.shadow_rays
+    assert linf(img, ref) < TOL
+    assert ref.max() > 0.05
+    scene.close()
+
+
+@pytest.mark.parametrize("mat", ["phong", "blinn-phong"])
+def test_image_parity_phong_family(dev, oracle, mat):
+    def edit(t):
+        out, k = [], 0
+        alphas = ["1", "5", "10", "20"]
+        lines = t.split("\n")
+        i = 0
+        while i < len(lines):
+            ln = lines[i]
+            if ln.strip() == 'type = "ggx"':
+                out.append(f'type = "{mat}"')
+            elif ln.startswith("roughness"):
+                out.append(f"alpha = {alphas[k]}"); k += 1
+            elif ln.startswith("ior"):
+                pass
+            else:
+                out.append(ln)
+            i += 1
+        return "\n".join(out)
+    desc = load("brdf-row.toml", 64, 36, text_edit=edit)
+    params = desc.render_params(spp=32, seed=5)
+    scene = dev.Scene(desc)
+    img = scene.render(params)
+    ref = oracle.render(desc, params)
+    both_nan = np.isnan(img) & np.isnan(ref)          # the reference's powf(negative, a) NaN, reproduced on both sides
+    assert np.array_equal(np.isnan(img), np.isnan(ref))
+    assert float(np.max(np.abs(np.where(both_nan, 0, img) - np.where(both_nan, 0, ref)))) < TOL
+    scene.close()
+
+
+def test_tiles_and_slots_do_not_change_the_image(dev):
+    """RNG is keyed by (seed, pixel, sample); chunking depends on spp only: any tiling, any slot count
+    and therefore any GPU count gives the same film bit for bit."""
+    from lumillyrender_amd import host
+    desc = load("cbox-spheres.toml", 50, 38)          # ragged against 16-pixel tiles
+    params = desc.render_params(spp=20, seed=3)
+    scene = dev.Scene(desc)
+    full = scene.render(params)
+    out = np.zeros_like(full)
+    for rank in range(3):
+        tiles, n = host.tiles(50, 38, 16, rank, 3)
+        scene.render(params, tiles, n, out=out)
+    assert np.array_equal(full, out)
+    p2 = desc.render_params(spp=20, seed=3, path_slots=512)
+    assert np.array_equal(full, scene.render(p2))
+    scene.close()
+
+
+def test_edge_cases(dev, oracle):
+    from lumillyrender_amd import abi, host
+    desc = load("cbox-spheres.toml", 8, 8)
+    scene = dev.Scene(desc)
+    params = desc.render_params(spp=1, seed=0)
+    # empty tile list, zero-area tiles: nothing is written
+    canvas = np.full((8, 8, 3), -1.0, dtype=np.float32)
+    tiles = (abi.LrTile * 2)()
+    tiles[0].x0, tiles[0].y0, tiles[0].w, tiles[0].h = 2, 2, 0, 3
+    tiles[1].x0, tiles[1].y0, tiles[1].w, tiles[1].h = 4, 4, 1, 1
+    scene.render(params, tiles, 0, out=canvas)
+    assert (canvas == -1).all()
+    scene.render(params, tiles, 2, out=canvas)
+    assert (canvas[4, 4] >= 0).all() and (np.delete(canvas.reshape(-1, 3), 4 * 8 + 4, axis=0) == -1).all()
+    # spp = 1 on a single pixel agrees with the oracle
+    ref = oracle.render(desc, params)
+    assert np.max(np.abs(canvas[4, 4] - ref[4, 4])) < TOL
+    # tile outside the film is rejected, not clipped
+    tiles[1].x0 = 8
+    with pytest.raises(host.LumillyError):
+        scene.render(params, tiles, 2, out=canvas)
+    scene.close()
