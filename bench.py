@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: Msamples/s of the per-pixel sampling loop on MI355X.
+
+Workload (BASELINE.json configs[1]): the reference's new-cbox scene (scenes/cbox-spheres.toml here),
+1024x1024, 1024 spp, pt-direct (next-event estimation), Lambert only.  One "step" = one full render
+of the frame through the C ABI (lr_render: wavefront kernels + film read-back).  The scene (BVH,
+primitives, materials, emitters) is resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU, pixel tiles of the frame sharded round-robin over ranks, scene
+replicated, no collective on the data path; the film tiles are summed onto rank 0 over gloo after
+each render (host gather).  --scaling weak (default) keeps per-GPU work fixed: the frame is rendered at
+1024*N spp, each rank owning 1/N of the pixels; --scaling strong keeps the frame at 1024 spp.
+
+The JSON line also carries
+  roofline     for the dominant kernel (k_trace): algorithmic bytes per launch / mean launch duration,
+               the duration measured with HIP events around the launches inside the timed region
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) on this box's host cores,
+               on a bounded sample of the same frame
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cbox-spheres.toml")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(desc, args):
+    """Oracle (kind 'port') on all host cores, literal reference traversal (bvh.rs/aabb.rs), on a
+    bounded sample: the same 1024x1024 frame at a reduced spp chosen to take ~cpu-seconds."""
+    from oracle import binding as oracle
+    cores = os.cpu_count() or 1
+    p = desc.render_params(spp=1, seed=0)
+    _, st = oracle.render(desc, p, threads=cores, mode=oracle.BVH, pad=0.0, with_stats=True)
+    rate1 = st.samples / max(st.seconds, 1e-9)
+    spp = int(max(1, min(64, args.cpu_seconds * rate1 / (args.width * args.height))))
+    p = desc.render_params(spp=spp, seed=0)
+    _, st = oracle.render(desc, p, threads=cores, mode=oracle.BVH, pad=0.0, with_stats=True)
+    return {
+        "value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"{args.width}x{args.height} frame at {spp} spp ({st.samples} samples, {st.seconds:.1f} s), "
+                  "oracle in reference-literal BVH mode, one thread per core",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    from lumillyrender_amd import abi, device, host
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev_index = local_rank if world > 1 else 0
+
+    W, H = args.width, args.height
+    spp = args.spp * (world if args.scaling == "weak" else 1)
+    desc = host.Description(os.path.join(ROOT, "scenes", args.scene))
+    desc.set_resolution(W, H)
+    scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
+    tiles, n_tiles = host.tiles(W, H, args.tile, rank, world)
+    flags = 0 if args.no_profile else abi.LR_FLAG_PROFILE
+    canvas = np.zeros((H, W, 3), dtype=np.float32)
+    barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if world > 1 else None
+
+    def barrier():
+        if dist is not None:
+            dist.all_reduce(barrier_buf)
+        torch.cuda.synchronize(dev_index)
+
+    def step(i):
+        params = desc.render_params(spp=spp, seed=i, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=flags, path_slots=args.slots)
+        scene.render(params, tiles, n_tiles, out=canvas)      # blocks until the film tiles are on the host
+        if dist is not None:
+            t = torch.from_numpy(canvas)
+            dist.reduce(t, dst=0)                              # host gather of the disjoint tiles (gloo)
+        return scene.stats()
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    acc = {"trace_ms": 0.0, "trace_timed": 0, "trace_launches": 0, "segments": 0, "shadow": 0, "samples": 0,
+           "kernel_ms": [0.0] * abi.LR_K_COUNT, "kernel_timed": [0] * abi.LR_K_COUNT, "iterations": 0, "render_ms": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(i)
+        acc["trace_ms"] += st.kernel_ms[abi.LR_K_TRACE]; acc["trace_timed"] += st.kernel_timed[abi.LR_K_TRACE]
+        acc["trace_launches"] += st.kernel_launches[abi.LR_K_TRACE]
+        acc["segments"] += st.segments; acc["shadow"] += st.shadow_rays; acc["samples"] += st.samples
+        acc["iterations"] += st.iterations; acc["render_ms"] += st.render_ms
+        for k in range(abi.LR_K_COUNT):
+            acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_samples = float(W) * H * spp * args.steps
+    value = total_samples / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        assert np.isfinite(canvas).all(), "non-finite film"
+        out = {
+            "metric": "Msamples/sec (whole node), new-cbox 1024x1024 pt-direct", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} (the reference's scenes/new-cbox.toml with authored Cornell meshes) "
+                            f"{W}x{H} {spp} spp pt-direct, Lambert only",
+                "width": W, "height": H, "spp": spp, "integrator": "pt-direct", "tile": args.tile,
+                "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, host gather",
+                "path_slots": args.slots or (1 << 20),
+            },
+        }
+        # ---- roofline of the dominant kernel (k_trace), N = 1 only -------------------------------------
+        if world == 1 and acc["trace_timed"] > 0:
+            # node visits / primitive tests per segment: one short counted render (same scene, same
+            # estimator; the ratios are per-segment averages and do not depend on spp)
+            pc = desc.render_params(spp=32, seed=77, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=abi.LR_FLAG_COUNT, path_slots=args.slots)
+            scene.render(pc, tiles, n_tiles, out=canvas)
+            sc = scene.stats()
+            v_per_seg = sc.node_visits / max(sc.segments, 1)
+            t_per_seg = sc.prim_tests / max(sc.segments, 1)
+            seg_per_launch = acc["segments"] / max(acc["trace_launches"], 1)
+            # DESIGN.md "algorithmic bytes": ray record read 32 B + hit record written 8 B + queue slot id
+            # written 4 B per segment, 32 B per child box tested, 48 B per primitive tested
+            bytes_per_seg = 32.0 + 8.0 + 4.0 + 32.0 * v_per_seg + 48.0 * t_per_seg
+            avg_ms = acc["trace_ms"] / acc["trace_timed"]
+            achieved = bytes_per_seg * seg_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("k_trace_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "k_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 5), "segments_per_launch": round(seg_per_launch, 1),
+                "bytes_per_segment": round(bytes_per_seg, 1), "node_boxes_per_segment": round(v_per_seg, 2),
+                "prim_tests_per_segment": round(t_per_seg, 2), "timed_launches": acc["trace_timed"],
+            }
+            names = abi.LR_KERNEL_NAMES
+            out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
+                                            for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
+            out["path_stats"] = {"segments_per_sample": round(acc["segments"] / acc["samples"], 3),
+                                 "shadow_rays_per_sample": round(acc["shadow"] / acc["samples"], 3),
+                                 "iterations_per_step": acc["iterations"] // max(args.steps, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, args)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,8 +166,10 @@ typedef struct LrStats {
   uint64_t samples;                  /* camera samples completed                             */
   uint64_t segments;                 /* S: closest-hit queries                               */
   uint64_t shadow_rays;              /* Q                                                    */
-  uint64_t node_visits;              /* V: child boxes tested        (LR_FLAG_COUNT)         */
-  uint64_t prim_tests;               /* T                            (LR_FLAG_COUNT)         */
+  uint64_t node_visits;              /* V: child boxes tested by closest-hit queries (LR_FLAG_COUNT) */
+  uint64_t prim_tests;               /* T: primitive tests of closest-hit queries    (LR_FLAG_COUNT) */
+  uint64_t shadow_node_visits;       /* same, shadow-ray queries                     (LR_FLAG_COUNT) */
+  uint64_t shadow_prim_tests;
   uint64_t sky_fetches;              /* M                                                    */
   uint64_t iterations;               /* wavefront loop iterations                            */
   uint64_t kernel_launches[LR_K_COUNT];

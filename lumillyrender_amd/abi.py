@@ -89,7 +89,8 @@ class LrTile(C.Structure):
 class LrStats(C.Structure):
     _fields_ = [
         ("samples", u64), ("segments", u64), ("shadow_rays", u64), ("node_visits", u64),
-        ("prim_tests", u64), ("sky_fetches", u64), ("iterations", u64),
+        ("prim_tests", u64), ("shadow_node_visits", u64), ("shadow_prim_tests", u64),
+        ("sky_fetches", u64), ("iterations", u64),
         ("kernel_launches", u64 * LR_K_COUNT),
         ("kernel_ms", C.c_double * LR_K_COUNT),
         ("kernel_timed", u64 * LR_K_COUNT),

@@ -32,7 +32,7 @@ constexpr int kNumShadeQueues = 6;
 constexpr int kQShadow = 6;
 constexpr int kCountersPerParity = 8;
 
-enum StatSlot { ST_SAMPLES = 0, ST_SEGMENTS, ST_SHADOW, ST_NODE_VISITS, ST_PRIM_TESTS, ST_SKY, ST_COUNT };
+enum StatSlot { ST_SAMPLES = 0, ST_SEGMENTS, ST_SHADOW, ST_NODE_VISITS, ST_PRIM_TESTS, ST_SHADOW_VISITS, ST_SHADOW_TESTS, ST_SKY, ST_COUNT };
 
 struct DevCamera {
   int type; int res_w, res_h;

@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, int
     }
   }
   wave_stat_add(st.stats + ST_SHADOW, n_q);
-  if (COUNT) { wave_stat_add(st.stats + ST_NODE_VISITS, n_vis); wave_stat_add(st.stats + ST_PRIM_TESTS, n_tst); }
+  if (COUNT) { wave_stat_add(st.stats + ST_SHADOW_VISITS, n_vis); wave_stat_add(st.stats + ST_SHADOW_TESTS, n_tst); }
 }
 
 __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, DevParams rp) {

@@ -292,7 +292,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.counters.ensure(2 * kCountersPerParity + 2);
   s.stats_dev.ensure(ST_COUNT + 2);
   s.partial.ensure(n_items);
-  s.film.ensure((size_t)W * H * 3);
+  if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
+    s.film.ensure((size_t)W * H * 3);
+    HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
+  }
   s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st);
   if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, 64 * sizeof(uint64_t)));
   if (!s.poll_ev[0]) { HIP_OK(hipEventCreate(&s.poll_ev[0])); HIP_OK(hipEventCreate(&s.poll_ev[1])); HIP_OK(hipEventCreate(&s.t_begin)); HIP_OK(hipEventCreate(&s.t_end)); }
@@ -384,6 +387,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   S.render_ms = ms;
   S.samples = hstats[ST_SAMPLES]; S.segments = hstats[ST_SEGMENTS]; S.shadow_rays = hstats[ST_SHADOW];
   S.node_visits = hstats[ST_NODE_VISITS]; S.prim_tests = hstats[ST_PRIM_TESTS]; S.sky_fetches = hstats[ST_SKY];
+  S.shadow_node_visits = hstats[ST_SHADOW_VISITS]; S.shadow_prim_tests = hstats[ST_SHADOW_TESTS];
   for (int k = 0; k < LR_K_COUNT; ++k) {
     EventPool& p = s.pools[k];
     for (int i = 0; i < p.used; ++i) { float e = 0.0f; HIP_OK(hipEventElapsedTime(&e, p.a[i], p.b[i])); S.kernel_ms[k] += e; }

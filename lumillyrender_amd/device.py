@@ -137,7 +137,7 @@ def selftest_rng(seed, pixel, sample, block, device=0):
 
 
 def stats_dict(s):
-    d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "sky_fetches", "iterations")}
+    d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests", "sky_fetches", "iterations")}
     d["render_ms"] = float(s.render_ms)
     d["upload_ms"] = float(s.upload_ms)
     d["kernels"] = {
