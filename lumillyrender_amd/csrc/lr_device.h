@@ -29,8 +29,9 @@ namespace lr {
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
-constexpr int kQShadow = 6;
-constexpr int kCountersPerParity = 8;
+constexpr int kSeg = 512;              // path slots per segment (queue / pool / counter granularity)
+constexpr int kStatShards = 64;        // statistics are sharded over 64 cache lines
+constexpr int kStatStride = 16;        // u64 words per shard (128 B)
 
 enum StatSlot { ST_SAMPLES = 0, ST_SEGMENTS, ST_SHADOW, ST_NODE_VISITS, ST_PRIM_TESTS, ST_SHADOW_VISITS, ST_SHADOW_TESTS, ST_SKY, ST_COUNT };
 
@@ -67,17 +68,20 @@ struct DevState {
   float4* ray_o; float4* ray_d; float2* hit;
   float4* thr;   float4* rad;   float4* acc;
   float4* sh_d;  float4* sh_w;
-  uint32_t* queues;                    // (kNumShadeQueues + 1) * n_slots slot indices
-  uint32_t* counters;                  // 2 parities * kCountersPerParity
-  uint32_t* next_item;                 // work-item dispenser
-  uint32_t* n_retired;                 // slots that found the dispenser empty
-  unsigned long long* stats;           // ST_COUNT
+  uint32_t* q_shade;                   // [queue][segment][kSeg] slot ids, written by k_trace
+  uint32_t* c_shade;                   // [queue][segment] counts
+  uint32_t* q_shadow;                  // [bsdf][segment][kSeg] slot ids with a pending shadow ray, written by k_shade<bsdf>
+  uint32_t* c_shadow;                  // [bsdf][segment] counts
+  uint4*    pool;                      // per-segment work-item pool {r0 next, r0 end, r1 next, r1 end}
+  uint32_t* next_item;                 // global work-item dispenser
+  uint32_t* n_retired;                 // slots that found pool and dispenser empty
+  unsigned long long* stats;           // kStatShards * kStatStride
   float4* partial;                     // n_items chunk sums
   float*  film;                        // W*H*3
   const int4* tiles;                   // x0, y0, w, h
   const uint32_t* tile_prefix;         // n_tiles + 1
   int n_tiles;
-  uint32_t n_slots, n_pix, n_chunks, chunk_spp, n_items;
+  uint32_t n_slots, n_seg, n_pix, n_chunks, chunk_spp, n_items;
   int stack_depth;                     // LDS traversal stack entries per lane
 };
 

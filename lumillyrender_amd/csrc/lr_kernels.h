@@ -22,17 +22,18 @@
 namespace lr {
 
 // ------------------------------------------------------------------------------------------
-// wave-level helpers
+// wave / workgroup helpers.  Queue heads, item pools and statistics are aggregated per 512-slot
+// segment in LDS: one global atomic per wave on a shared word costs ~12 ns and serialises (the first
+// version of these kernels spent >90 % of its time there), an LDS atomic does not.
 // ------------------------------------------------------------------------------------------
 LR_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 LR_DEV uint32_t rank_in_mask(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Reserve popcount(pred) consecutive entries with ONE atomic per wave; returns this lane's index.
-// Must be reached by the whole (converged) wave.
-LR_DEV uint32_t wave_reserve(uint32_t* counter, bool pred, uint64_t* mask_out = nullptr) {
+// Reserve popcount(pred) consecutive entries with ONE atomic per wave (on an LDS or global word);
+// returns this lane's index.  Must be reached by the whole (converged) wave.
+LR_DEV uint32_t wave_reserve(uint32_t* counter, bool pred) {
   uint64_t mask = __ballot(pred);
-  if (mask_out) *mask_out = mask;
   if (mask == 0) return 0;
   uint32_t leader = (uint32_t)__builtin_ctzll(mask);
   uint32_t base = 0;
@@ -40,14 +41,15 @@ LR_DEV uint32_t wave_reserve(uint32_t* counter, bool pred, uint64_t* mask_out = 
   base = __shfl(base, (int)leader, 64);
   return base + rank_in_mask(mask);
 }
-LR_DEV void queue_push(uint32_t* queue, uint32_t* counter, bool pred, uint32_t value) {
-  uint32_t idx = wave_reserve(counter, pred);
-  if (pred) queue[idx] = value;
-}
-LR_DEV void wave_stat_add(unsigned long long* stat, uint32_t v) {
-  // sum over the wave, one atomic
+// per-lane counter -> workgroup total in LDS (flushed to a sharded global counter at kernel end)
+LR_DEV void stat_accumulate(uint32_t* lds_stat, uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if (lane_id() == 0 && v) atomicAdd(stat, (unsigned long long)v);
+  if (lane_id() == 0 && v) atomicAdd(lds_stat, v);
+}
+LR_DEV void stat_flush(unsigned long long* stats, const uint32_t* lds_stat) {
+  // call after __syncthreads(); 64 shards of kStatStride words spread the atomics over L2 channels
+  if (threadIdx.x < ST_COUNT && lds_stat[threadIdx.x])
+    atomicAdd(stats + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride + threadIdx.x, (unsigned long long)lds_stat[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,11 +506,38 @@ LR_DEV void start_sample(const DevScene& sc, const DevState& st, const DevParams
   st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
 }
 
+// Per-segment pool of work items (the device end of the pixel tile queue).  Each segment keeps up to
+// two ranges of item ids it reserved from the global dispenser; thread 0 tops the pool up at the
+// start of a segment pass so that the pass can never run short (at most one item per slot per
+// pass), lanes then draw from it with LDS atomics only.
+struct PoolLds { uint32_t r0, a0, r1, a1, taken; };
+
+LR_DEV void pool_begin(const DevState& st, uint32_t seg, uint32_t need_max, PoolLds* pl, bool reset) {
+  uint4 p = reset ? make_uint4(0, 0, 0, 0) : st.pool[seg];       // {r0 next, r0 end, r1 next, r1 end}
+  if (p.x >= p.y) { p.x = p.z; p.y = p.w; p.z = p.w = 0; }
+  if (p.y - p.x < need_max && p.z >= p.w) {
+    uint32_t cur = __hip_atomic_load(st.next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur < st.n_items) {
+      uint32_t nb = atomicAdd(st.next_item, (uint32_t)kSeg);
+      if (nb < st.n_items) { p.z = nb; p.w = nb + kSeg < st.n_items ? nb + kSeg : st.n_items; }
+    }
+    if (p.x >= p.y) { p.x = p.z; p.y = p.w; p.z = p.w = 0; }
+  }
+  pl->r0 = p.x; pl->a0 = p.y - p.x; pl->r1 = p.z; pl->a1 = p.w - p.z; pl->taken = 0;
+}
+LR_DEV void pool_end(const DevState& st, uint32_t seg, const PoolLds* pl) {
+  uint32_t t0 = pl->taken < pl->a0 ? pl->taken : pl->a0;
+  uint32_t rest = pl->taken - t0;
+  uint32_t t1 = rest < pl->a1 ? rest : pl->a1;
+  st.pool[seg] = make_uint4(pl->r0 + t0, pl->r0 + pl->a0, pl->r1 + t1, pl->r1 + pl->a1);
+}
+
 // End-of-path bookkeeping for the whole wave (main.rs:92-121): fold the finished sample into the
-// chunk sum, hand out new work items with one atomic per wave, start the next camera sample.
+// chunk sum, draw new work items from the segment pool, start the next camera sample.
 //   finished : this lane's path just ended with radiance L (sample index `sample`, pixel `pixel`)
 //   fresh    : this lane has no work item yet (k_generate)
-LR_DEV void finish_and_regenerate(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot,
+// Returns true when the lane found the pool (and the dispenser) empty and retired its slot.
+LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const DevParams& rp, PoolLds* pl, uint32_t slot,
                                   bool finished, bool fresh, V3 L, float g_term, uint32_t pixel, uint32_t sample) {
   bool need_item = fresh;
   uint32_t item = 0;
@@ -525,17 +554,18 @@ LR_DEV void finish_and_regenerate(const DevScene& sc, const DevState& st, const 
     if (end > (uint32_t)rp.spp) end = (uint32_t)rp.spp;
     if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
   }
-  uint64_t mask;
-  uint32_t new_item = wave_reserve(st.next_item, need_item, &mask);
+  uint32_t k = wave_reserve(&pl->taken, need_item);
   bool retired = false;
   if (need_item) {
-    if (new_item < st.n_items) {
-      item = new_item;
+    if (k < pl->a0) item = pl->r0 + k;
+    else if (k - pl->a0 < pl->a1) item = pl->r1 + (k - pl->a0);
+    else retired = true;
+    if (!retired) {
       uint32_t rank = item % st.n_pix, chunk = item / st.n_pix;
       pixel = item_pixel(st, sc.cam, rank);
       sample = chunk * st.chunk_spp;
       sum = v3(0, 0, 0);
-    } else retired = true;
+    }
   }
   if (finished || fresh) {
     if (retired) {
@@ -545,36 +575,45 @@ LR_DEV void finish_and_regenerate(const DevScene& sc, const DevState& st, const 
       start_sample(sc, st, rp, slot, pixel, sample);
     }
   }
-  uint32_t idx = wave_reserve(st.n_retired, retired);
-  (void)idx;
+  return retired;
 }
 
 // ==========================================================================================
-// kernels
+// kernels.  Every kernel walks 512-slot segments (grid-stride over segments, 256 threads).
 // ==========================================================================================
 __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, DevParams rp) {
-  uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t base = blockIdx.x * kBlock; base < st.n_slots; base += stride) {
-    uint32_t slot = base + threadIdx.x;
-    bool valid = slot < st.n_slots;
-    finish_and_regenerate(sc, st, rp, valid ? slot : 0, false, valid, v3(0, 0, 0), 1.0f, 0, 0);
+  __shared__ PoolLds pl;
+  __shared__ uint32_t s_retired;
+  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+    if (threadIdx.x == 0) { pool_begin(st, seg, kSeg, &pl, true); s_retired = 0; }
+    __syncthreads();
+    for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+      uint32_t slot = seg * kSeg + step * kBlock + threadIdx.x;
+      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, false, true, v3(0, 0, 0), 1.0f, 0, 0);
+      (void)wave_reserve(&s_retired, r);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { pool_end(st, seg, &pl); if (s_retired) atomicAdd(st.n_retired, s_retired); }
+    __syncthreads();
   }
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, int parity) {
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st) {
   extern __shared__ uint32_t lds[];
+  __shared__ uint32_t s_cnt[8];
+  __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
   float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
-  uint32_t* cnt = st.counters + parity * kCountersPerParity;
-  if (blockIdx.x == 0 && threadIdx.x < kCountersPerParity) st.counters[(parity ^ 1) * kCountersPerParity + threadIdx.x] = 0;   // next iteration's counters
-  uint32_t stride = gridDim.x * kBlock;
+  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_seg = 0, n_vis = 0, n_tst = 0;
-  for (uint32_t base = blockIdx.x * kBlock; base < st.n_slots; base += stride) {
-    uint32_t slot = base + threadIdx.x;
-    bool active = false;
-    int qid = -1;
-    if (slot < st.n_slots) {
+  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+      uint32_t slot = seg * kSeg + step * kBlock + threadIdx.x;
+      bool active = false;
+      int qid = -1;
       float4 ro = st.ray_o[slot];
       if (__float_as_int(ro.w) >= 0) {
         float4 rd = st.ray_d[slot];
@@ -585,121 +624,155 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, int 
         n_seg += 1;
         if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
       }
+      // compaction: one list per BSDF (and one for misses) per segment, order-preserving within the wave
+      uint64_t todo = __ballot(active);
+      while (todo) {
+        int lead = (int)__builtin_ctzll(todo);
+        int q = __shfl(qid, lead, 64);
+        bool mine = active && qid == q;
+        uint32_t idx = wave_reserve(&s_cnt[q], mine);
+        if (mine) st.q_shade[((size_t)q * st.n_seg + seg) * kSeg + idx] = slot;
+        todo &= ~__ballot(mine);
+      }
     }
-    // compaction: one queue per BSDF (and one for misses), order-preserving within the wave
-    uint64_t todo = __ballot(active);
-    while (todo) {
-      int lead = (int)__builtin_ctzll(todo);
-      int q = __shfl(qid, lead, 64);
-      bool mine = active && qid == q;
-      queue_push(st.queues + (size_t)q * st.n_slots, cnt + q, mine, slot);
-      todo &= ~__ballot(mine);
-    }
+    __syncthreads();
+    if (threadIdx.x < kNumShadeQueues) st.c_shade[threadIdx.x * st.n_seg + seg] = s_cnt[threadIdx.x];
+    __syncthreads();
   }
-  wave_stat_add(st.stats + ST_SEGMENTS, n_seg);
-  if (COUNT) { wave_stat_add(st.stats + ST_NODE_VISITS, n_vis); wave_stat_add(st.stats + ST_PRIM_TESTS, n_tst); }
+  stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
+  if (COUNT) { stat_accumulate(&s_stat[ST_NODE_VISITS], n_vis); stat_accumulate(&s_stat[ST_PRIM_TESTS], n_tst); }
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
 }
 
 // MT in 0..4 = BSDF of the hit material; MT == kQMiss = sky
 template <int MT>
-__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevParams rp, int parity) {
-  uint32_t* cnt = st.counters + parity * kCountersPerParity;
-  const uint32_t n = cnt[MT];
-  const uint32_t* queue = st.queues + (size_t)MT * st.n_slots;
-  uint32_t* shadow_q = st.queues + (size_t)kQShadow * st.n_slots;
-  uint32_t stride = gridDim.x * kBlock;
+__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevParams rp) {
+  __shared__ PoolLds pl;
+  __shared__ uint32_t s_shadow, s_retired;
+  __shared__ uint32_t s_stat[ST_COUNT];
+  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
   const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
-    uint32_t i = base + threadIdx.x;
-    bool valid = i < n;
-    uint32_t slot = valid ? queue[i] : 0;
-    bool finished = false, has_shadow = false;
-    V3 L = v3(0, 0, 0); float g_term = 1.0f; uint32_t pixel = 0, sample = 0;
-    if (valid) {
-      float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
-      int depth = __float_as_int(ro.w);
-      pixel = __float_as_uint(th.w); sample = __float_as_uint(ra.w);
-      V3 o = v3(ro), d = v3(rd), T = v3(th);
-      L = v3(ra); g_term = rd.w;
-      if (MT == kQMiss) {                                              // scene.rs:29 / :43
-        L = L + T * sky_radiance(sc, d);
-        if (sc.sky_type == LR_SKY_IBL) n_sky += 1;
-        finished = true;
-      } else {
-        float2 h = st.hit[slot];
-        float t = h.x; int prim = __float_as_int(h.y);
-        V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
-        float4 sh = sc.shade[prim];
-        uint32_t mw = __float_as_uint(sh.w);
-        V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
-        uint32_t mi = mw & 0x7fffffffu;
-        Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
-        V3 out_ = -d;
-        V3 emission = v3(m.m1);
-        bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
-        if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
-          L = L + T * emission;
-        float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
-        Draw4 d1 = rng_block(rp.seed, pixel, sample, 1u + 2u * (uint32_t)depth);
-        if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
+  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+    const uint32_t n = st.c_shade[MT * st.n_seg + seg];
+    const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + seg) * kSeg;
+    uint32_t* shadow_q = st.q_shadow + ((size_t)(MT == kQMiss ? 0 : MT) * st.n_seg + seg) * kSeg;
+    if (threadIdx.x == 0) { pool_begin(st, seg, n, &pl, false); s_shadow = 0; s_retired = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kBlock) {
+      uint32_t i = base + threadIdx.x;
+      bool valid = i < n;
+      uint32_t slot = valid ? queue[i] : 0;
+      bool finished = false, has_shadow = false;
+      V3 L = v3(0, 0, 0); float g_term = 1.0f; uint32_t pixel = 0, sample = 0;
+      if (valid) {
+        float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
+        int depth = __float_as_int(ro.w);
+        pixel = __float_as_uint(th.w); sample = __float_as_uint(ra.w);
+        V3 o = v3(ro), d = v3(rd), T = v3(th);
+        L = v3(ra); g_term = rd.w;
+        if (MT == kQMiss) {                                              // scene.rs:29 / :43
+          L = L + T * sky_radiance(sc, d);
+          if (sc.sky_type == LR_SKY_IBL) n_sky += 1;
           finished = true;
         } else {
-          // ---- direct light (scene.rs:104-151), the occlusion test itself runs in k_shadow ----
-          if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
-            V3 lp; float lpdf;
-            sample_emission(sc, d1, &lp, &lpdf);
-            V3 direct_path = lp - pos;
-            float d2 = sqr_norm(direct_path);
-            float dist = __builtin_sqrtf(d2);
-            V3 dir = direct_path / dist;
-            V3 point_normal = orienting_normal(out_, nrm);
-            float point_cos = dot(dir, point_normal);
-            if (point_cos > 0.0f) {
-              V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
-              V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
-              st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
-              st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
-              has_shadow = true;
+          float2 h = st.hit[slot];
+          float t = h.x; int prim = __float_as_int(h.y);
+          V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
+          float4 sh = sc.shade[prim];
+          uint32_t mw = __float_as_uint(sh.w);
+          V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
+          uint32_t mi = mw & 0x7fffffffu;
+          Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
+          V3 out_ = -d;
+          V3 emission = v3(m.m1);
+          bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
+          if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
+            L = L + T * emission;
+          float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
+          Draw4 d1 = rng_block(rp.seed, pixel, sample, 1u + 2u * (uint32_t)depth);
+          if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
+            finished = true;
+          } else {
+            // ---- direct light (scene.rs:104-151), the occlusion test itself runs in k_shadow ----
+            if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
+              V3 lp; float lpdf;
+              sample_emission(sc, d1, &lp, &lpdf);
+              V3 direct_path = lp - pos;
+              float d2 = sqr_norm(direct_path);
+              float dist = __builtin_sqrtf(d2);
+              V3 dir = direct_path / dist;
+              V3 point_normal = orienting_normal(out_, nrm);
+              float point_cos = dot(dir, point_normal);
+              if (point_cos > 0.0f) {
+                V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
+                V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
+                st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
+                st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
+                has_shadow = true;
+              }
             }
+            // ---- BSDF sample (scene.rs:78-102) ----
+            Draw4 d2r = rng_block(rp.seed, pixel, sample, 2u + 2u * (uint32_t)depth);
+            V3 in_; float pdf;
+            material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
+            V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
+            V3 coef = material_coef<MT>(m, out_, nrm, t);
+            float c = dot(in_, nrm);
+            V3 f = brdf * coef * c / pdf / p;
+            T = T * f;
+            st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
+            st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, g_term);
+            st.thr[slot] = make_float4(T.x, T.y, T.z, th.w);
+            st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
           }
-          // ---- BSDF sample (scene.rs:78-102) ----
-          Draw4 d2r = rng_block(rp.seed, pixel, sample, 2u + 2u * (uint32_t)depth);
-          V3 in_; float pdf;
-          material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
-          V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
-          V3 coef = material_coef<MT>(m, out_, nrm, t);
-          float c = dot(in_, nrm);
-          V3 f = brdf * coef * c / pdf / p;
-          T = T * f;
-          st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
-          st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, g_term);
-          st.thr[slot] = make_float4(T.x, T.y, T.z, th.w);
-          st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
         }
       }
+      if (finished) n_done += 1;
+      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, finished, false, L, g_term, pixel, sample);
+      (void)wave_reserve(&s_retired, r);
+      if (MT != kQMiss) {
+        uint32_t idx = wave_reserve(&s_shadow, has_shadow);
+        if (has_shadow) shadow_q[idx] = slot;
+      }
     }
-    if (finished) n_done += 1;
-    finish_and_regenerate(sc, st, rp, slot, finished, false, L, g_term, pixel, sample);
-    queue_push(shadow_q, cnt + kQShadow, has_shadow, slot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      pool_end(st, seg, &pl);
+      if (MT != kQMiss) st.c_shadow[MT * st.n_seg + seg] = s_shadow;
+      if (s_retired) atomicAdd(st.n_retired, s_retired);
+    }
+    __syncthreads();
   }
-  wave_stat_add(st.stats + ST_SAMPLES, n_done);
-  if (MT == kQMiss) wave_stat_add(st.stats + ST_SKY, n_sky);
+  stat_accumulate(&s_stat[ST_SAMPLES], n_done);
+  if (MT == kQMiss) stat_accumulate(&s_stat[ST_SKY], n_sky);
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
 }
 
+// mt_mask: BSDF types present in the scene (their k_shade wrote this iteration's shadow lists)
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, int parity) {
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask) {
   extern __shared__ uint32_t lds[];
+  __shared__ uint32_t s_pref[kNumShadeQueues];
+  __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
   float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
-  const uint32_t n = st.counters[parity * kCountersPerParity + kQShadow];
-  const uint32_t* queue = st.queues + (size_t)kQShadow * st.n_slots;
-  uint32_t stride = gridDim.x * kBlock;
+  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_q = 0, n_vis = 0, n_tst = 0;
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
-    uint32_t i = base + threadIdx.x;
-    if (i < n) {
-      uint32_t slot = queue[i];
+  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+    if (threadIdx.x == 0) {
+      uint32_t acc = 0;
+      for (int k = 0; k < kNumShadeQueues - 1; ++k) { s_pref[k] = acc; if (mt_mask & (1u << k)) acc += st.c_shadow[k * st.n_seg + seg]; }
+      s_pref[kNumShadeQueues - 1] = acc;
+    }
+    __syncthreads();
+    const uint32_t n = s_pref[kNumShadeQueues - 1];
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+      int k = 0;
+      while (k < kNumShadeQueues - 2 && i >= s_pref[k + 1]) ++k;
+      uint32_t slot = st.q_shadow[((size_t)k * st.n_seg + seg) * kSeg + (i - s_pref[k])];
       // NOTE: shade already advanced ray_o to the hit point, which is the shadow ray origin (scene.rs:114-117)
       float4 ro = st.ray_o[slot];
       float4 sd = st.sh_d[slot];
@@ -722,9 +795,12 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, int
         }
       }
     }
+    __syncthreads();
   }
-  wave_stat_add(st.stats + ST_SHADOW, n_q);
-  if (COUNT) { wave_stat_add(st.stats + ST_SHADOW_VISITS, n_vis); wave_stat_add(st.stats + ST_SHADOW_TESTS, n_tst); }
+  stat_accumulate(&s_stat[ST_SHADOW], n_q);
+  if (COUNT) { stat_accumulate(&s_stat[ST_SHADOW_VISITS], n_vis); stat_accumulate(&s_stat[ST_SHADOW_TESTS], n_tst); }
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
 }
 
 __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, DevParams rp) {

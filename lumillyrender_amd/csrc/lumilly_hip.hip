@@ -74,7 +74,8 @@ struct LrScene {
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
-  DevBuf<uint32_t> queues, counters, tile_prefix;
+  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix;
+  DevBuf<uint4> pool;
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
   DevBuf<float> film;
@@ -236,7 +237,7 @@ int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   per_cu = std::min(per_cu, 8);
-  long long want = ((long long)work_items + kBlock - 1) / kBlock;
+  long long want = ((long long)work_items + kBlock - 1) / kBlock;   // callers pass segments * kBlock for segment kernels
   long long cap = (long long)n_cus * per_cu;
   return (int)std::max<long long>(1, std::min(want, cap));
 }
@@ -282,22 +283,25 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
   const uint32_t n_items = (uint32_t)n_items64;
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (1u << 20);
-  n_slots = std::max<uint32_t>(kBlock, std::min<uint32_t>(n_slots, ((n_items + kBlock - 1) / kBlock) * kBlock));
-  n_slots = (n_slots + kBlock - 1) / kBlock * kBlock;
+  n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
+  n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
+  const uint32_t n_seg = n_slots / kSeg;
 
   hipStream_t st = s.stream;
   s.ray_o.ensure(n_slots); s.ray_d.ensure(n_slots); s.hit.ensure(n_slots); s.thr.ensure(n_slots); s.rad.ensure(n_slots);
   s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
-  s.queues.ensure((size_t)(kNumShadeQueues + 1) * n_slots);
-  s.counters.ensure(2 * kCountersPerParity + 2);
-  s.stats_dev.ensure(ST_COUNT + 2);
+  s.q_shade.ensure((size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
+  s.q_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
+  s.pool.ensure(n_seg);
+  s.counters.ensure(4);
+  s.stats_dev.ensure((size_t)kStatShards * kStatStride);
   s.partial.ensure(n_items);
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
     HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
   }
   s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st);
-  if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, 64 * sizeof(uint64_t)));
+  if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, (8 + 2 * kStatShards * kStatStride) * sizeof(uint64_t)));
   if (!s.poll_ev[0]) { HIP_OK(hipEventCreate(&s.poll_ev[0])); HIP_OK(hipEventCreate(&s.poll_ev[1])); HIP_OK(hipEventCreate(&s.t_begin)); HIP_OK(hipEventCreate(&s.t_end)); }
   const bool profile = (rp_in.flags & LR_FLAG_PROFILE) != 0, count = (rp_in.flags & LR_FLAG_COUNT) != 0;
   if (profile) for (auto& p : s.pools) p.init();
@@ -305,11 +309,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
 
   DevState ds; std::memset(&ds, 0, sizeof(ds));
   ds.ray_o = s.ray_o.p; ds.ray_d = s.ray_d.p; ds.hit = s.hit.p; ds.thr = s.thr.p; ds.rad = s.rad.p; ds.acc = s.acc.p;
-  ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p; ds.queues = s.queues.p; ds.counters = s.counters.p;
-  ds.next_item = s.counters.p + 2 * kCountersPerParity; ds.n_retired = ds.next_item + 1;
+  ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p;
+  ds.q_shade = s.q_shade.p; ds.c_shade = s.c_shade.p; ds.q_shadow = s.q_shadow.p; ds.c_shadow = s.c_shadow.p; ds.pool = s.pool.p;
+  ds.next_item = s.counters.p; ds.n_retired = s.counters.p + 1;
   ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p;
   ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size();
-  ds.n_slots = n_slots; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
+  ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
   DevParams dp; dp.integrator = rp_in.integrator; dp.spp = rp_in.spp; dp.seed = rp_in.seed; dp.depth = rp_in.depth;
   dp.depth_limit = rp_in.depth_limit; dp.no_direct_emitter = rp_in.no_direct_emitter ? 1 : 0;
@@ -318,49 +323,51 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   double keep_upload = S.upload_ms;
   std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload;
 
-  HIP_OK(hipMemsetAsync(s.counters.p, 0, (2 * kCountersPerParity + 2) * sizeof(uint32_t), st));
-  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, (ST_COUNT + 2) * sizeof(unsigned long long), st));
+  HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
+  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
   const size_t lds = (size_t)s.stack_depth * kBlock * 8;
   const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
   const void* kshadow = count ? (const void*)k_shadow<true> : (const void*)k_shadow<false>;
-  const int g_trace = grid_for(ktrace, s.n_cus, lds, n_slots);
-  const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_slots);
-  const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_slots);
+  const int g_trace = grid_for(ktrace, s.n_cus, lds, n_seg * kBlock);
+  const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
+  const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_seg * kBlock);
   int g_shade[kNumShadeQueues];
-  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_slots);
-  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_slots);
-  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_slots);
-  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_slots);
-  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_slots);
-  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_slots);
+  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_seg * kBlock);
+  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_seg * kBlock);
+  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_seg * kBlock);
+  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_seg * kBlock);
+  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_seg * kBlock);
+  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_seg * kBlock);
 
   Launcher L{s, profile};
   if (n_items > 0) {
     L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, s.dev, ds, dp); });
     const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
     const int kCheck = 8;
-    int parity = 0, batch = 0;
+    int batch = 0;
+    uint32_t mt_mask = 0;
+    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     bool done = false;
     // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
     // length statistically, this bounds the loop against a logic error
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, parity); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, parity); });
-        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
-        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
-        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
-        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
-        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
-        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp, parity); });
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds); });
+        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, parity); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, parity); });
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask); });
         }
-        parity ^= 1; L.iter++; S.iterations++;
+        L.iter++; S.iterations++;
       }
       // poll the retired-slot counter one batch behind so the queue never drains
       HIP_OK(hipMemcpyAsync(&s.pinned[batch & 1], ds.n_retired, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -380,9 +387,11 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, s.dev, ds, dp); });
   }
   HIP_OK(hipEventRecord(s.t_end, st));
-  unsigned long long* hstats = (unsigned long long*)(s.pinned + 8);
-  HIP_OK(hipMemcpyAsync(hstats, s.stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
+  HIP_OK(hipMemcpyAsync(hshards, s.stats_dev.p, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+  unsigned long long hstats[ST_COUNT] = {0};
+  for (int sh = 0; sh < kStatShards; ++sh) for (int k = 0; k < ST_COUNT; ++k) hstats[k] += hshards[sh * kStatStride + k];
   float ms = 0.0f; HIP_OK(hipEventElapsedTime(&ms, s.t_begin, s.t_end));
   S.render_ms = ms;
   S.samples = hstats[ST_SAMPLES]; S.segments = hstats[ST_SEGMENTS]; S.shadow_rays = hstats[ST_SHADOW];
@@ -442,7 +451,7 @@ int lr_scene_destroy(LrScene* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   s->nodes.release(); s->prims.release(); s->shade.release(); s->mats.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->hit.release(); s->queues.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release();
+  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release();
   s->stats_dev.release(); s->film.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
