@@ -79,7 +79,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    from lumillyrender_amd import abi, device, host
+    from lumillyrender_amd import abi, device, host, multigpu
 
     dist = None
     if world > 1:
@@ -96,7 +96,7 @@ def main():
     desc = host.Description(os.path.join(ROOT, "scenes", args.scene))
     desc.set_resolution(W, H)
     scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
-    tiles, n_tiles = host.tiles(W, H, args.tile, rank, world)
+    tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
     flags = 0 if args.no_profile else abi.LR_FLAG_PROFILE
     canvas = np.zeros((H, W, 3), dtype=np.float32)
     barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if world > 1 else None
@@ -109,10 +109,9 @@ def main():
     def step(i):
         params = desc.render_params(spp=spp, seed=i, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=flags, path_slots=args.slots)
         scene.render(params, tiles, n_tiles, out=canvas)      # blocks until the film tiles are on the host
-        if dist is not None:
-            t = torch.from_numpy(canvas)
-            dist.reduce(t, dst=0)                              # host gather of the disjoint tiles (gloo)
-        return scene.stats()
+        st = scene.stats()
+        multigpu.gather_film(canvas, dist, dst=0)              # host gather of the disjoint tiles (gloo)
+        return st
 
     for i in range(args.warmup):
         step(1000 + i)

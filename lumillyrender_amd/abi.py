@@ -99,14 +99,6 @@ class LrStats(C.Structure):
     ]
 
 
-class LrOracleStats(C.Structure):
-    """oracle/lr_oracle.cpp: struct LrOracleStats (tests / cpu_baseline only)."""
-    _fields_ = [
-        ("samples", u64), ("segments", u64), ("shadow_rays", u64), ("node_visits", u64),
-        ("prim_tests", u64), ("sky_fetches", u64), ("seconds", C.c_double),
-    ]
-
-
 # ---- include/lumilly_host.h -------------------------------------------------------------------
 class LrRendererConfig(C.Structure):
     _fields_ = [

@@ -15,6 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 from lumillyrender_amd import abi  # noqa: E402  (POD struct mirrors only)
 
+
+
+class LrOracleStats(C.Structure):
+    """lr_oracle.cpp: struct LrOracleStats"""
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
+                ("prim_tests", C.c_uint64), ("sky_fetches", C.c_uint64), ("seconds", C.c_double)]
+
+
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 _lib = None
 fp = C.POINTER(C.c_float)
@@ -32,7 +40,7 @@ def lib():
         build()
     l = C.CDLL(_LIB_PATH)
     l.lr_oracle_render.argtypes = [C.POINTER(abi.LrSceneDesc), C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int,
-                                   fp, C.c_size_t, C.c_int, C.c_int, C.c_float, C.POINTER(abi.LrOracleStats)]
+                                   fp, C.c_size_t, C.c_int, C.c_int, C.c_float, C.POINTER(LrOracleStats)]
     l.lr_oracle_triangle_intersect.argtypes = [fp, fp, fp, C.c_int, fp]
     l.lr_oracle_sphere_intersect.argtypes = [fp, C.c_float, fp, fp, fp]
     l.lr_oracle_reflect.argtypes = [fp, fp, fp]
@@ -93,7 +101,7 @@ def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE,
         tiles[0].x0, tiles[0].y0, tiles[0].w, tiles[0].h = 0, 0, w, h
         n_tiles = 1
     img = np.zeros((h, w, 3), dtype=np.float32)
-    st = abi.LrOracleStats()
+    st = LrOracleStats()
     rc = lib().lr_oracle_render(description.desc_ptr, C.byref(params), tiles, n_tiles, img.ctypes.data_as(fp), w * 3,
                                 threads, mode, pad, C.byref(st))
     if rc != 0:

@@ -1,0 +1,340 @@
+"""The C++ host (scene loader, BVH builder, tile queue, film output) against the Python restatement
+of the reference front end (oracle/scene_ref.py) and against direct expectations."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from lumillyrender_amd import abi, host
+from oracle import scene_ref
+from tests.conftest import ROOT, scene_path
+
+REF_SCENES = sorted(glob.glob("/root/reference/scenes/*.toml"))
+OWN_SCENES = sorted(glob.glob(os.path.join(ROOT, "scenes", "*.toml")))
+HAVE_GENERATED = os.path.exists(os.path.join(host.ASSET_ROOT, "models/blob/blob.obj")) and \
+    os.path.exists(os.path.join(host.ASSET_ROOT, "models/ibl/sky_3k.hdr"))
+
+
+def _loadable(path):
+    t = open(path).read()
+    if "bunny" in t or "dragon" in t or "models/ibl" in t and "sky_3k" not in t:
+        return False          # reference assets that do not exist anywhere
+    if ("blob.obj" in t or "sky_3k" in t) and not HAVE_GENERATED:
+        return False
+    return True
+
+
+def _compare(path):
+    d = host.Description(path)
+    got = d.dump()
+    want = scene_ref.load(path, host.ASSET_ROOT)
+    for k in ("samples", "depth", "depth_limit", "no_direct_emitter", "threads", "integrator"):
+        assert got["renderer"][k] == want["renderer"][k], k
+    assert got["film"]["resolution"] == want["film"]["resolution"] and got["film"]["output"] == want["film"]["output"]
+    assert np.float32(got["film"]["gamma"]) == want["film"]["gamma"]
+    cg, cw = got["camera"], want["camera"]
+    assert cg["type"] == cw["type"]
+    for k in ("forward", "right", "up", "position", "aperture_position"):
+        assert np.array_equal(np.array(cg[k], np.float32), cw[k]), k
+    if cw["type"] != 2:
+        # tan() comes from libm on one side and from math.tan on the other: <= 1 ulp
+        assert np.allclose(np.array(cg["sensor_size"], np.float32), cw["sensor_size"], rtol=2e-7)
+        assert np.float32(cg["aperture_sensor_distance"]) == cw["aperture_sensor_distance"]
+    if cw["type"] == 1:
+        for k in ("aperture_radius", "focus_distance"):
+            assert np.float32(cg[k]) == cw[k], k
+        assert np.isclose(cg["sensor_sensitivity"], cw["sensor_sensitivity"], rtol=1e-6)
+    assert len(got["materials"]) == len(want["materials"])
+    for a, b in zip(got["materials"], want["materials"]):
+        assert a["type"] == b["type"]
+        assert np.array_equal(np.array(a["color"], np.float32), b["color"])
+        assert np.array_equal(np.array(a["emission"], np.float32), b["emission"])
+        assert np.array_equal(np.array(a["param"], np.float32), np.array(b["param"], np.float32))
+    assert got["n_prims"] == len(want["prims"])
+    for a, b in zip(got["prims"], want["prims"]):
+        assert a["type"] == b["type"] and a["material"] == b["material"]
+        # rotations go through cosf/sinf (libm vs math): allow 1e-4 absolute on ~500-unit coordinates
+        assert np.allclose(np.array(a["v"], np.float32), b["v"], rtol=0, atol=2e-4)
+    return got
+
+
+@pytest.mark.skipif(not REF_SCENES, reason="/root/reference is not present on this machine")
+@pytest.mark.parametrize("path", REF_SCENES, ids=[os.path.basename(p) for p in REF_SCENES])
+def test_reference_scene_files(path):
+    """Every scenes/*.toml of the reference either loads identically to the restated front end or
+    fails with 'file not found' for an asset that was never published."""
+    if _loadable(path):
+        _compare(path)
+    else:
+        with pytest.raises(host.LumillyError) as e:
+            host.Description(path)
+        assert e.value.code == abi.LR_EIO and "is not found" in str(e.value)
+
+
+@pytest.mark.parametrize("path", OWN_SCENES, ids=[os.path.basename(p) for p in OWN_SCENES])
+def test_own_scene_files(path):
+    if not _loadable(path):
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    _compare(path)
+
+
+@pytest.mark.skipif(not REF_SCENES, reason="/root/reference is not present on this machine")
+def test_authored_scenes_equal_reference_scenes():
+    """scenes/cbox-spheres.toml and brdf-row.toml are the reference's new-cbox.toml / brdf.toml
+    re-authored in another TOML style: the flattened descriptions must be identical."""
+    for own, ref in (("cbox-spheres.toml", "new-cbox.toml"), ("brdf-row.toml", "brdf.toml")):
+        a = host.Description(scene_path(own)).dump()
+        b = host.Description(os.path.join("/root/reference/scenes", ref)).dump()
+        assert a == b
+
+
+def test_thin_lens_accepts_both_key_spellings():
+    base = open(scene_path("cbox-spheres.toml")).read()
+    cam = 'type = "thin-lens"\nfov = 39.3077\n{}\n{}\n'
+    for fd, fn in (("focus-distance = 900", "f-number = 1.8"), ("focus_distance = 900", "f_number = 1.8")):
+        t = base.replace('type = "ideal-pinhole"\nfov = 39.3077\n', cam.format(fd, fn))
+        d = host.Description(text=t)
+        c = d.dump(0)["camera"]
+        assert c["type"] == 1 and c["focus_distance"] == 900 and c["aperture_radius"] > 0
+    with pytest.raises(host.LumillyError):
+        host.Description(text=base.replace('type = "ideal-pinhole"\nfov = 39.3077\n', 'type = "thin-lens"\nfov = 39.3077\n'))
+
+
+BASE = """
+[renderer]
+samples = 4
+[film]
+resolution = [8, 6]
+output = "png"
+[camera]
+type = "ideal-pinhole"
+fov = 40
+"""
+
+
+def test_defaults_and_errors():
+    d = host.Description(text=BASE)
+    r, f = d.renderer, d.film
+    assert (r.samples, r.depth, r.depth_limit, r.no_direct_emitter, r.integrator) == (4, 5, 64, 0, abi.LR_INTEGRATOR_PT_DIRECT)
+    assert abs(f.gamma - 2.2) < 1e-6 and d.desc.n_prims == 0 and d.desc.sky.type == abi.LR_SKY_UNIFORM
+    assert d.desc.n_bvh_nodes == 1                         # empty scene still has a root
+    bad = [
+        BASE.replace("samples = 4", ""),                                   # missing required field
+        BASE.replace('output = "png"', 'output = "exr"'),                   # main.rs:165-167
+        BASE + '[[object]]\nmesh = "nope"\n',                               # scene_loader.rs:241
+        BASE + '[[mesh]]\nname = "s"\ntype = "sphere"\nradius = 1\n[[object]]\nmesh = "s"\n',   # description.rs:139
+        BASE + '[[mesh]]\nname = "s"\ntype = "sphere"\nradius = 1\n[[object]]\nmesh = "s"\nmaterial = "m"\n',
+        BASE.replace("samples = 4", "samples = 4.5"),                       # usize from a float
+        BASE.replace("samples = 4", 'samples = 4\nintegrator = "bdpt"'),    # main.rs:124
+        BASE.replace("fov = 40", "fov = [1]"),
+        "this is not toml ===",
+    ]
+    for t in bad:
+        with pytest.raises(host.LumillyError):
+            host.Description(text=t)
+    with pytest.raises(host.LumillyError) as e:
+        host.Description("/nonexistent/scene.toml")
+    assert e.value.code == abi.LR_EIO
+
+
+def test_light_binding_and_emission_only_on_lambert():
+    t = BASE + """
+[[light]]
+type = "area"
+object = "a"
+emission = [1, 2, 3]
+intensity = 2
+[[light]]
+type = "area"
+object = "b"
+emission = [5, 5, 5]
+[[mesh]]
+name = "s"
+type = "sphere"
+radius = 2
+[[material]]
+name = "l"
+type = "lambert"
+albedo = [0.5, 0.25, 1]
+[[material]]
+name = "g"
+type = "ggx"
+reflectance = [1, 1, 1]
+roughness = 0.5
+ior = 1.5
+[[object]]
+name = "a"
+mesh = "s"
+material = "l"
+transform = [ { type = "scale", vector = [3, 3, 3] }, { type = "translate", vector = [1, 2, 3] } ]
+[[object]]
+name = "b"
+mesh = "s"
+material = "g"
+[[object]]
+mesh = "s"
+material = "l"
+"""
+    j = host.Description(text=t).dump()
+    assert j["materials"][0]["emission"] == [2, 4, 6]       # emission * intensity (scene_loader.rs:259)
+    assert j["materials"][1]["emission"] == [0, 0, 0]       # non-Lambert never emits (description.rs:103-130)
+    assert j["materials"][2]["emission"] == [0, 0, 0]       # unnamed object never binds
+    assert j["prims"][0]["v"] == [1, 2, 3, 2]               # centre = M * 0, radius NOT scaled (description.rs:137-141)
+
+
+def test_toml_syntax_coverage():
+    t = """
+# comment
+title = 'literal \\ string'
+[renderer]   # trailing comment
+samples = 1_000
+"depth" = 0x10
+depth-limit = 0o17
+[film]
+resolution = [
+  4,   # width
+  2,
+]
+output = "h\\u0064r"
+gamma = 1e0
+[camera]
+type = "omnidirectional"
+transform = [{type = "look-at", origin = [0.0, +1.0, -2.5e0], target = [0, 0, 0], up = [0, 1, 0]}]
+"""
+    d = host.Description(text=t)
+    assert d.renderer.samples == 1000 and d.renderer.depth == 16 and d.renderer.depth_limit == 15
+    assert d.film.output == 1 and d.film.gamma == 1.0 and d.desc.camera.type == abi.LR_CAMERA_OMNIDIRECTIONAL
+    for bad in ('a = 1\na = 2\n' + BASE, BASE + '[renderer]\nsamples = 2\nx = """multi"""\n', BASE.replace("samples = 4", "samples = 2020-01-01")):
+        with pytest.raises(host.LumillyError):
+            host.Description(text=bad)
+
+
+def test_obj_loader_forms(tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nnewmtl b\nKd 0.9 0.8 0.7\n")
+    (tmp_path / "m.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nvn 0 0 1\nvt 0 0\n"
+        "g first\nusemtl a\nf 1/1/1 2/1/1 3/1/1 4/1/1 5/1/1\n"      # pentagon -> 3 triangles, fan from vertex 1
+        "usemtl b\nf -5 -4 -3\n"                                      # relative indices, material change splits the model
+        "g second\nf 1//1 3//1 4//1\n")                               # keeps material b
+    t = BASE + f'[[mesh]]\nname = "m"\ntype = "obj"\npath = "{tmp_path}/m.obj"\n[[object]]\nmesh = "m"\n'
+    j = host.Description(text=t).dump()
+    assert j["n_prims"] == 5
+    assert [p["material"] for p in j["prims"]] == [0, 0, 0, 1, 1]
+    assert j["materials"][0]["color"] == pytest.approx([0.1, 0.2, 0.3]) and j["materials"][1]["color"] == pytest.approx([0.9, 0.8, 0.7])
+    assert j["prims"][1]["v"] == [0, 0, 0, 1, 1, 0, 0, 1, 0]       # (v1, v3, v4)
+    assert j["prims"][3]["v"] == [0, 0, 0, 1, 0, 0, 1, 1, 0]
+    # a face without material and no object material is an error (description.rs:176-179)
+    (tmp_path / "n.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    with pytest.raises(host.LumillyError):
+        host.Description(text=BASE + f'[[mesh]]\nname = "m"\ntype = "obj"\npath = "{tmp_path}/n.obj"\n[[object]]\nmesh = "m"\n')
+
+
+def _check_bvh(desc):
+    """Every primitive appears exactly once; every stored child box contains its primitives."""
+    d = desc.desc
+    prims = [d.prims[i] for i in range(d.n_prims)]
+    seen = np.zeros(d.n_prims, dtype=int)
+    depth_seen = [0]
+
+    def prim_bounds(p):
+        v = np.array(p.v[:], dtype=np.float64)
+        if p.type == abi.LR_PRIM_TRIANGLE:
+            pts = v.reshape(3, 3)
+            return pts.min(0), pts.max(0)
+        return v[:3] - v[3], v[:3] + v[3]
+
+    def walk(ref, lo, hi, depth):
+        if ref >= 0:
+            n = d.bvh_nodes[ref]
+            depth_seen[0] = max(depth_seen[0], depth + 1)
+            for side in range(2):
+                clo = np.array([n.x[2 * side], n.y[2 * side], n.z[2 * side]])
+                chi = np.array([n.x[2 * side + 1], n.y[2 * side + 1], n.z[2 * side + 1]])
+                walk(n.child[side], clo, chi, depth + 1)
+        else:
+            enc = ~ref
+            first, count = enc >> 3, enc & 7
+            for k in range(first, first + count):
+                pid = d.bvh_prim_order[k]
+                seen[pid] += 1
+                plo, phi = prim_bounds(prims[pid])
+                assert np.all(plo >= lo) and np.all(phi <= hi)
+    walk(0, np.full(3, -np.inf), np.full(3, np.inf), 0)
+    assert np.all(seen == 1)
+    assert depth_seen[0] <= d.bvh_max_depth
+
+
+def test_bvh_structure():
+    for name in ("cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"):
+        _check_bvh(host.Description(scene_path(name)))
+    # single primitive and empty scene
+    one = BASE + '[[mesh]]\nname = "s"\ntype = "sphere"\nradius = 1\n[[material]]\nname = "l"\ntype = "lambert"\nalbedo = [1,1,1]\n[[object]]\nmesh = "s"\nmaterial = "l"\n'
+    _check_bvh(host.Description(text=one))
+    _check_bvh(host.Description(text=BASE))
+
+
+def test_bvh_standalone_many_triangles():
+    rng = np.random.default_rng(4)
+    n = 3000
+    prims = (abi.LrPrimitive * n)()
+    for i in range(n):
+        c = rng.random(3) * 100
+        pts = c + rng.standard_normal((3, 3))
+        prims[i].type = abi.LR_PRIM_TRIANGLE
+        prims[i].v[:] = [float(x) for x in pts.reshape(-1)]
+    nodes, nn, order, depth = host.build_bvh(prims, n, max_leaf=4)
+    assert sorted(order[:n]) == list(range(n)) and 1 <= depth <= 60 and nn < n
+
+
+def test_tiles_partition_the_film():
+    W, H, T = 70, 45, 16
+    for world in (1, 2, 3, 8):
+        cover = np.zeros((H, W), dtype=int)
+        for rank in range(world):
+            tiles, n = host.tiles(W, H, T, rank, world)
+            for i in range(n):
+                t = tiles[i]
+                assert t.w > 0 and t.h > 0 and t.x0 + t.w <= W and t.y0 + t.h <= H
+                cover[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] += 1
+        assert np.all(cover == 1)
+    with pytest.raises(host.LumillyError):
+        host.tiles(W, H, T, 3, 3)
+
+
+def test_png_output_matches_to_color(tmp_path):
+    """main.rs:171-173: clamp, pow(1/gamma), *255, TRUNCATE; img.rs:52-63: RGB8, row 0 on top."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = (rng.random((9, 13, 3)) * 1.4 - 0.2).astype(np.float32)
+    img[0, 0] = [np.nan, -1.0, 2.0]
+    img[0, 1] = [0.5, 1.0, 0.0]
+    p = tmp_path / "o.png"
+    host.save_png(p, img, gamma=2.2)
+    got = np.array(Image.open(p).convert("RGB"))
+    c = np.clip(np.nan_to_num(img.astype(np.float64), nan=0.0), 0, 1)
+    want = np.floor(np.float32(c.astype(np.float32) ** np.float32(1 / 2.2)) * np.float32(255.0))
+    assert np.max(np.abs(got.astype(int) - want.astype(int))) <= 1          # powf last-bit differences at bucket edges
+    assert (got == want).mean() > 0.99
+    assert tuple(got[0, 0]) == (0, 0, 255) and got[0, 1, 1] == 255 and got[0, 1, 2] == 0
+    assert np.array_equal(host.to_color(img, 2.2), got)
+
+
+def test_hdr_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    img = (rng.random((7, 40, 3)) ** 4 * 50).astype(np.float32)
+    img[2, :20] = 0.0                                                       # a run for the RLE
+    img[3, 5] = [1e-6, 0, 0]
+    p = tmp_path / "o.hdr"
+    host.save_hdr(p, img)
+    back = host.load_hdr(p)
+    assert back.shape == img.shape
+    mx = img.max(axis=2, keepdims=True)
+    assert np.all(np.abs(back - img) <= np.maximum(mx, 1e-30) / 128 + 1e-30)   # 8-bit mantissa, truncated
+    assert np.all(back[2, :20] == 0)
+    # narrow images are written flat (no RLE below 8 pixels)
+    host.save_hdr(p, img[:, :5])
+    assert host.load_hdr(p).shape == (7, 5, 3)
+    with pytest.raises(host.LumillyError):
+        host.load_hdr(tmp_path / "missing.hdr")
