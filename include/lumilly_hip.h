@@ -151,6 +151,8 @@ typedef struct LrRenderParams {
 
 #define LR_FLAG_PROFILE 1            /* bracket kernel launches with HIP events (lr_get_stats) */
 #define LR_FLAG_COUNT   2            /* count segments / shadow rays / node visits / prim tests */
+#define LR_FLAG_STREAMING 4          /* force the multi-kernel streaming pipeline (state in HBM)      */
+#define LR_FLAG_RESIDENT  8          /* force the single-launch resident pipeline (state in LDS) if it fits */
 
 typedef struct LrTile { int32_t x0, y0, w, h; } LrTile;
 
@@ -160,7 +162,8 @@ typedef struct LrTile { int32_t x0, y0, w, h; } LrTile;
 #define LR_K_SHADE    2
 #define LR_K_SHADOW   3
 #define LR_K_RESOLVE  4
-#define LR_K_COUNT    5
+#define LR_K_RESIDENT 5              /* the resident pipeline's single launch (trace/shade/shadow phases) */
+#define LR_K_COUNT    6
 
 typedef struct LrStats {
   uint64_t samples;                  /* camera samples completed                             */

@@ -29,6 +29,7 @@ namespace lr {
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
+constexpr int kFlatMax = 32;          // scenes up to this many primitives skip the tree
 constexpr int kSeg = 512;              // path slots per segment (queue / pool / counter granularity)
 constexpr int kStatShards = 64;        // statistics are sharded over 64 cache lines
 constexpr int kStatStride = 16;        // u64 words per shard (128 B)
@@ -51,6 +52,7 @@ struct DevScene {
   const float4* emit;
   const float4* texels;
   const uint8_t* prim_qid;             // per primitive id: shade queue (= material type)
+  int   n_flat;                        // > 0: test all n_flat primitives with scalar loads instead of walking the tree
   int   n_emitters;
   float emission_area;
   int   sky_type;

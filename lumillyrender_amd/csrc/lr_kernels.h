@@ -181,6 +181,33 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
   return res;
 }
 
+// Small scenes (n_flat = number of primitives when <= kFlatMax, else 0): the SAH says a tree over a
+// dozen primitives saves almost nothing, so the "tree" is one leaf and every lane tests every
+// primitive.  The loop index is wave-uniform, so the primitive rows arrive through the scalar cache
+// into SGPRs (s_load_dwordx4) and the loop is pure, fully converged VALU: no vector memory traffic,
+// no stack, no divergence.  Same tests, same tie rule => same result as traverse().
+template <bool SHADOW>
+LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, int n, V3 o, V3 d, float dist) {
+  TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = 0;
+  for (int k = 0; k < n; ++k) {
+    float4 q0 = prims[3 * k], q1 = prims[3 * k + 1];
+    uint32_t idw = __float_as_uint(q0.w);
+    int id = (int)(idw & 0x7fffffffu);
+    float t; bool hit;
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+    else { float4 q2 = prims[3 * k + 2]; hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t); }
+    if (SHADOW) {
+      float diff = t - dist;
+      if (hit && diff < -kEps) res.occluded = true;
+      hit = hit && !(diff > kEps);
+      if (__ballot(!res.occluded) == 0) break;               // every lane already knows it is occluded
+    }
+    if (hit && (t < res.t || (t == res.t && id < res.prim))) { res.t = t; res.prim = id; }
+  }
+  res.tests = (uint32_t)n;
+  return res;
+}
+
 // ------------------------------------------------------------------------------------------
 // util.rs
 // ------------------------------------------------------------------------------------------
@@ -599,7 +626,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st) {
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_cnt[8];
   __shared__ uint32_t s_stat[ST_COUNT];
@@ -618,7 +645,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st) {
       if (__float_as_int(ro.w) >= 0) {
         float4 rd = st.ray_d[slot];
         active = true;
-        TraceResult r = traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
+        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
         st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
         qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
         n_seg += 1;
@@ -645,7 +672,100 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st) {
   stat_flush(st.stats, s_stat);
 }
 
-// MT in 0..4 = BSDF of the hit material; MT == kQMiss = sky
+// One path vertex (scene.rs:153-193): MT in 0..4 = BSDF of the hit material, MT == kQMiss = sky.
+// Reads the slot's ray / hit / throughput / radiance, handles emission, Russian roulette, the
+// direct-light sample (its occlusion test is left to the shadow stage: *has_shadow) and the BSDF sample.
+// Returns true when the path ended here; L / g_term / pixel / sample then describe the finished sample.
+// `st` may point at global memory (streaming pipeline) or at LDS (resident pipeline).
+struct VertexOut { bool finished, has_shadow; V3 L; float g_term; uint32_t pixel, sample; bool sky_fetch; };
+
+template <int MT>
+LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot) {
+  VertexOut out; out.finished = false; out.has_shadow = false; out.sky_fetch = false;
+  const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
+  float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
+  int depth = __float_as_int(ro.w);
+  out.pixel = __float_as_uint(th.w); out.sample = __float_as_uint(ra.w);
+  V3 o = v3(ro), d = v3(rd), T = v3(th);
+  V3 L = v3(ra); out.g_term = rd.w;
+  if (MT == kQMiss) {                                              // scene.rs:29 / :43
+    L = L + T * sky_radiance(sc, d);
+    out.sky_fetch = sc.sky_type == LR_SKY_IBL;
+    out.finished = true;
+  } else {
+    float2 h = st.hit[slot];
+    float t = h.x; int prim = __float_as_int(h.y);
+    V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
+    float4 sh = sc.shade[prim];
+    uint32_t mw = __float_as_uint(sh.w);
+    V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
+    uint32_t mi = mw & 0x7fffffffu;
+    Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
+    V3 out_ = -d;
+    V3 emission = v3(m.m1);
+    bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
+    if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
+      L = L + T * emission;
+    float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
+    Draw4 d1 = rng_block(rp.seed, out.pixel, out.sample, 1u + 2u * (uint32_t)depth);
+    if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
+      out.finished = true;
+    } else {
+      // ---- direct light (scene.rs:104-151); the occlusion test itself is the shadow stage ----
+      if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
+        V3 lp; float lpdf;
+        sample_emission(sc, d1, &lp, &lpdf);
+        V3 direct_path = lp - pos;
+        float d2 = sqr_norm(direct_path);
+        float dist = __builtin_sqrtf(d2);
+        V3 dir = direct_path / dist;
+        V3 point_normal = orienting_normal(out_, nrm);
+        float point_cos = dot(dir, point_normal);
+        if (point_cos > 0.0f) {
+          V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
+          V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
+          st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
+          st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
+          out.has_shadow = true;
+        }
+      }
+      // ---- BSDF sample (scene.rs:78-102) ----
+      Draw4 d2r = rng_block(rp.seed, out.pixel, out.sample, 2u + 2u * (uint32_t)depth);
+      V3 in_; float pdf;
+      material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
+      V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
+      V3 coef = material_coef<MT>(m, out_, nrm, t);
+      float c = dot(in_, nrm);
+      V3 f = brdf * coef * c / pdf / p;
+      T = T * f;
+      st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
+      st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, out.g_term);
+      st.thr[slot] = make_float4(T.x, T.y, T.z, th.w);
+      st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
+    }
+  }
+  out.L = L;
+  return out;
+}
+
+// The shadow stage for one slot (scene.rs:127-147): adds the direct-light term if the sampled point is visible.
+LR_DEV void shadow_resolve(const DevScene& sc, const DevState& st, uint32_t slot, V3 o, V3 dir, const TraceResult& r) {
+  if (!r.occluded && r.prim >= 0) {                                // scene.rs:127-131
+    V3 pos = o + dir * r.t;
+    float4 sh = sc.shade[r.prim];
+    uint32_t mw = __float_as_uint(sh.w);
+    V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
+    float light_cos = dot(-dir, light_normal);
+    if (light_cos > 0.0f) {                                        // scene.rs:133-139
+      V3 l_i = v3(sc.mats[3 * (mw & 0x7fffffffu) + 1]);           // emission of what was hit (scene.rs:144)
+      float4 w = st.sh_w[slot];
+      float4 ra = st.rad[slot];
+      V3 L = v3(ra) + v3(w) * l_i * light_cos;
+      st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
+    }
+  }
+}
+
 template <int MT>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevParams rp) {
   __shared__ PoolLds pl;
@@ -653,7 +773,6 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   __shared__ uint32_t s_stat[ST_COUNT];
   if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
-  const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
   for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
     const uint32_t n = st.c_shade[MT * st.n_seg + seg];
     const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + seg) * kSeg;
@@ -664,77 +783,15 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
       uint32_t i = base + threadIdx.x;
       bool valid = i < n;
       uint32_t slot = valid ? queue[i] : 0;
-      bool finished = false, has_shadow = false;
-      V3 L = v3(0, 0, 0); float g_term = 1.0f; uint32_t pixel = 0, sample = 0;
-      if (valid) {
-        float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
-        int depth = __float_as_int(ro.w);
-        pixel = __float_as_uint(th.w); sample = __float_as_uint(ra.w);
-        V3 o = v3(ro), d = v3(rd), T = v3(th);
-        L = v3(ra); g_term = rd.w;
-        if (MT == kQMiss) {                                              // scene.rs:29 / :43
-          L = L + T * sky_radiance(sc, d);
-          if (sc.sky_type == LR_SKY_IBL) n_sky += 1;
-          finished = true;
-        } else {
-          float2 h = st.hit[slot];
-          float t = h.x; int prim = __float_as_int(h.y);
-          V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
-          float4 sh = sc.shade[prim];
-          uint32_t mw = __float_as_uint(sh.w);
-          V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
-          uint32_t mi = mw & 0x7fffffffu;
-          Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
-          V3 out_ = -d;
-          V3 emission = v3(m.m1);
-          bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
-          if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
-            L = L + T * emission;
-          float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
-          Draw4 d1 = rng_block(rp.seed, pixel, sample, 1u + 2u * (uint32_t)depth);
-          if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
-            finished = true;
-          } else {
-            // ---- direct light (scene.rs:104-151), the occlusion test itself runs in k_shadow ----
-            if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
-              V3 lp; float lpdf;
-              sample_emission(sc, d1, &lp, &lpdf);
-              V3 direct_path = lp - pos;
-              float d2 = sqr_norm(direct_path);
-              float dist = __builtin_sqrtf(d2);
-              V3 dir = direct_path / dist;
-              V3 point_normal = orienting_normal(out_, nrm);
-              float point_cos = dot(dir, point_normal);
-              if (point_cos > 0.0f) {
-                V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
-                V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
-                st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
-                st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
-                has_shadow = true;
-              }
-            }
-            // ---- BSDF sample (scene.rs:78-102) ----
-            Draw4 d2r = rng_block(rp.seed, pixel, sample, 2u + 2u * (uint32_t)depth);
-            V3 in_; float pdf;
-            material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
-            V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
-            V3 coef = material_coef<MT>(m, out_, nrm, t);
-            float c = dot(in_, nrm);
-            V3 f = brdf * coef * c / pdf / p;
-            T = T * f;
-            st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
-            st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, g_term);
-            st.thr[slot] = make_float4(T.x, T.y, T.z, th.w);
-            st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
-          }
-        }
-      }
-      if (finished) n_done += 1;
-      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, finished, false, L, g_term, pixel, sample);
+      VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
+      if (valid) v = shade_vertex<MT>(sc, st, rp, slot);
+      if (v.finished) n_done += 1;
+      if (v.sky_fetch) n_sky += 1;
+      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample);
       (void)wave_reserve(&s_retired, r);
       if (MT != kQMiss) {
-        uint32_t idx = wave_reserve(&s_shadow, has_shadow);
-        if (has_shadow) shadow_q[idx] = slot;
+        uint32_t idx = wave_reserve(&s_shadow, v.has_shadow);
+        if (v.has_shadow) shadow_q[idx] = slot;
       }
     }
     __syncthreads();
@@ -753,7 +810,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 
 // mt_mask: BSDF types present in the scene (their k_shade wrote this iteration's shadow lists)
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask) {
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_pref[kNumShadeQueues];
   __shared__ uint32_t s_stat[ST_COUNT];
@@ -777,23 +834,10 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
       float4 ro = st.ray_o[slot];
       float4 sd = st.sh_d[slot];
       V3 o = v3(ro), dir = v3(sd);
-      TraceResult r = traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
+      TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
       n_q += 1;
       if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
-      if (!r.occluded && r.prim >= 0) {                                // scene.rs:127-131
-        V3 pos = o + dir * r.t;
-        float4 sh = sc.shade[r.prim];
-        uint32_t mw = __float_as_uint(sh.w);
-        V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
-        float light_cos = dot(-dir, light_normal);
-        if (light_cos > 0.0f) {                                        // scene.rs:133-139
-          V3 l_i = v3(sc.mats[3 * (mw & 0x7fffffffu) + 1]);           // emission of what was hit (scene.rs:144)
-          float4 w = st.sh_w[slot];
-          float4 ra = st.rad[slot];
-          V3 L = v3(ra) + v3(w) * l_i * light_cos;
-          st.rad[slot] = make_float4(L.x, L.y, L.z, ra.w);
-        }
-      }
+      shadow_resolve(sc, st, slot, o, dir, r);
     }
     __syncthreads();
   }
@@ -801,6 +845,146 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
   if (COUNT) { stat_accumulate(&s_stat[ST_SHADOW_VISITS], n_vis); stat_accumulate(&s_stat[ST_SHADOW_TESTS], n_tst); }
   __syncthreads();
   stat_flush(st.stats, s_stat);
+}
+
+// ==========================================================================================
+// Resident pipeline: ONE launch for the whole render.  A workgroup owns one 512-slot segment from the
+// first camera sample to its last retired slot and keeps the segment's whole path state in LDS
+// (ray, hit, throughput, radiance, chunk sum, shadow record: 120 B x 512 = 60 KB, two workgroups per
+// CU).  The stages of the streaming pipeline survive as PHASES separated by workgroup barriers:
+//   trace (all live slots, compaction into per-BSDF lists with __ballot / mbcnt prefix sums)
+//   -> shade<BSDF> per list (regeneration from the segment's item pool) -> shadow list.
+// Segments never exchange data (only the global item dispenser and the chunk-sum array are shared), so
+// there is no grid barrier and no path-state traffic to HBM at all.  Used when the LDS budget allows
+// (small traversal stacks); results are bit-identical to the streaming pipeline (same device
+// functions, same RNG keys, same chunk order).
+// ==========================================================================================
+LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need) {
+  uint32_t t0 = pl->taken < pl->a0 ? pl->taken : pl->a0;
+  pl->r0 += t0; pl->a0 -= t0;
+  uint32_t rest = pl->taken - t0;
+  uint32_t t1 = rest < pl->a1 ? rest : pl->a1;
+  pl->r1 += t1; pl->a1 -= t1;
+  pl->taken = 0;
+  if (pl->a0 == 0) { pl->r0 = pl->r1; pl->a0 = pl->a1; pl->a1 = 0; }
+  if (pl->a0 < need && pl->a1 == 0) {
+    uint32_t cur = __hip_atomic_load(st.next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur < st.n_items) {
+      uint32_t nb = atomicAdd(st.next_item, (uint32_t)kSeg);
+      if (nb < st.n_items) { pl->r1 = nb; pl->a1 = st.n_items - nb < (uint32_t)kSeg ? st.n_items - nb : (uint32_t)kSeg; }
+    }
+    if (pl->a0 == 0) { pl->r0 = pl->r1; pl->a0 = pl->a1; pl->a1 = 0; }
+  }
+}
+
+template <int MT>
+LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const DevParams& rp, PoolLds* pl,
+                                const uint16_t* list, uint32_t n, uint16_t* shadow_list, uint32_t* shadow_cnt,
+                                uint32_t* retired_cnt, uint32_t* n_done, uint32_t* n_sky) {
+  for (uint32_t base = 0; base < n; base += kBlock) {
+    uint32_t i = base + threadIdx.x;
+    bool valid = i < n;
+    uint32_t slot = valid ? list[i] : 0;
+    VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
+    if (valid) v = shade_vertex<MT>(sc, st, rp, slot);
+    if (v.finished) *n_done += 1;
+    if (v.sky_fetch) *n_sky += 1;
+    bool r = finish_and_regenerate(sc, st, rp, pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample);
+    (void)wave_reserve(retired_cnt, r);
+    if (MT != kQMiss) {
+      uint32_t idx = wave_reserve(shadow_cnt, v.has_shadow);
+      if (v.has_shadow) shadow_list[idx] = (uint16_t)slot;
+    }
+  }
+}
+
+constexpr int kResidentStateBytes = 7 * kSeg * 16 + kSeg * 8 + 7 * kSeg * 2;   // 68608
+
+__global__ void __launch_bounds__(kBlock, 2) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+  extern __shared__ float4 lds4[];
+  __shared__ PoolLds pl;
+  __shared__ uint32_t s_cnt[8];            // [0..5] shade lists, [6] shadow list
+  __shared__ uint32_t s_retired;
+  __shared__ uint32_t s_stat[ST_COUNT];
+  DevState st = gst;
+  st.ray_o = lds4; st.ray_d = lds4 + kSeg; st.thr = lds4 + 2 * kSeg; st.rad = lds4 + 3 * kSeg;
+  st.acc = lds4 + 4 * kSeg; st.sh_d = lds4 + 5 * kSeg; st.sh_w = lds4 + 6 * kSeg;
+  st.hit = (float2*)(lds4 + 7 * kSeg);
+  uint16_t* lists = (uint16_t*)(st.hit + kSeg);                     // [7][kSeg]
+  uint32_t* stk_n = (uint32_t*)(lists + 7 * kSeg);
+  float* stk_t = (float*)(stk_n + (size_t)gst.stack_depth * kBlock);
+  const uint32_t tid = threadIdx.x;
+  if (tid < ST_COUNT) s_stat[tid] = 0;
+  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kSeg); s_retired = 0; }
+  __syncthreads();
+  for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+    bool r = finish_and_regenerate(sc, st, rp, &pl, step * kBlock + tid, false, true, v3(0, 0, 0), 1.0f, 0, 0);
+    (void)wave_reserve(&s_retired, r);
+  }
+  uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;
+  while (true) {
+    __syncthreads();
+    if (s_retired >= (uint32_t)kSeg) break;                        // wave-uniform: read after the barrier
+    __syncthreads();
+    if (tid < 8) s_cnt[tid] = 0;
+    __syncthreads();
+    // ---- phase 1: closest hit for every live slot, compaction by BSDF ----
+    for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+      uint32_t slot = step * kBlock + tid;
+      bool active = false; int qid = -1;
+      float4 ro = st.ray_o[slot];
+      if (__float_as_int(ro.w) >= 0) {
+        float4 rd = st.ray_d[slot];
+        active = true;
+        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
+        st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
+        qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
+        n_seg += 1;
+      }
+      uint64_t todo = __ballot(active);
+      while (todo) {
+        int lead = (int)__builtin_ctzll(todo);
+        int q = __shfl(qid, lead, 64);
+        bool mine = active && qid == q;
+        uint32_t idx = wave_reserve(&s_cnt[q], mine);
+        if (mine) lists[q * kSeg + idx] = (uint16_t)slot;
+        todo &= ~__ballot(mine);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {                                                 // at most one new item per live slot this iteration
+      uint32_t need = 0;
+      for (int q = 0; q < kNumShadeQueues; ++q) need += s_cnt[q];
+      pool_step(st, &pl, need);
+    }
+    __syncthreads();
+    // ---- phase 2: one BSDF-specialised body per list ----
+    uint16_t* shq = lists + 6 * kSeg;
+    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, &pl, lists + 0 * kSeg, s_cnt[0], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, &pl, lists + 1 * kSeg, s_cnt[1], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, &pl, lists + 2 * kSeg, s_cnt[2], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, &pl, lists + 3 * kSeg, s_cnt[3], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, &pl, lists + 4 * kSeg, s_cnt[4], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    resident_shade_list<kQMiss>(sc, st, rp, &pl, lists + 5 * kSeg, s_cnt[5], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    __syncthreads();
+    // ---- phase 3: shadow rays of this iteration ----
+    const uint32_t nsh = s_cnt[6];
+    for (uint32_t i = tid; i < nsh; i += kBlock) {
+      uint32_t slot = shq[i];
+      float4 ro = st.ray_o[slot];
+      float4 sd = st.sh_d[slot];
+      V3 o = v3(ro), dir = v3(sd);
+      TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
+      n_shq += 1;
+      shadow_resolve(sc, st, slot, o, dir, r);
+    }
+  }
+  stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
+  stat_accumulate(&s_stat[ST_SHADOW], n_shq);
+  stat_accumulate(&s_stat[ST_SAMPLES], n_done);
+  stat_accumulate(&s_stat[ST_SKY], n_sky);
+  __syncthreads();
+  stat_flush(gst.stats, s_stat);
 }
 
 __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, DevParams rp) {
@@ -840,14 +1024,14 @@ __global__ void k_selftest_rng(uint32_t seed, const uint32_t* pixel, const uint3
   Draw4 d = rng_block(seed, pixel[i], sample[i], block[i]);
   out4[4 * i] = d.v[0]; out4[4 * i + 1] = d.v[1]; out4[4 * i + 2] = d.v[2]; out4[4 * i + 3] = d.v[3];
 }
-__global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, int stack_depth, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
+__global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, const float4* __restrict__ flat_prims, int stack_depth, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
   extern __shared__ uint32_t lds[];
   uint32_t* stk_n = lds;
   float* stk_t = (float*)(lds + (size_t)stack_depth * kBlock);
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-  TraceResult r = traverse<false>(sc, o, d, 0.0f, stk_n, stk_t);
+  TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, stk_t);
   prim_out[i] = r.prim; t_out[i] = r.prim >= 0 ? r.t : 0.0f;
 }
 

@@ -214,6 +214,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   std::memset(&v, 0, sizeof(v));
   v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.mats = s.mats.p; v.emit = s.emit.p;
   v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
+  v.n_flat = (np > 0 && np <= kFlatMax) ? np : 0;
   v.n_emitters = (int)emitters.size(); v.emission_area = emission_area;
   v.sky_type = d.sky.type; v.sky_color[0] = d.sky.color[0]; v.sky_color[1] = d.sky.color[1]; v.sky_color[2] = d.sky.color[2];
   v.sky_h = d.sky.height; v.sky_lon = d.sky.longitude_offset;
@@ -244,7 +245,7 @@ int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
 
 struct Launcher {
   LrScene& s; bool profile; int iter = 0;
-  bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
+  bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || k == LR_K_RESIDENT || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
   template <class F> void run(int k, F&& launch) {
     bool t = timed(k);
     EventPool& p = s.pools[k];
@@ -282,7 +283,16 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   uint64_t n_items64 = (uint64_t)n_pix * n_chunks;
   if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
   const uint32_t n_items = (uint32_t)n_items64;
-  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (1u << 20);
+  const bool count = (rp_in.flags & LR_FLAG_COUNT) != 0;
+  // pipeline: resident (one launch, path state in LDS) when two workgroups fit a CU's 160 KB of LDS
+  const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 8;
+  const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
+  bool resident = resident_lds <= 80 * 1024 && !count;
+  if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
+  if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
+  const int resident_per_cu = resident_lds <= 80 * 1024 ? 2 : 1;
+  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kSeg) : (1u << 20));
+  if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -303,7 +313,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st);
   if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, (8 + 2 * kStatShards * kStatStride) * sizeof(uint64_t)));
   if (!s.poll_ev[0]) { HIP_OK(hipEventCreate(&s.poll_ev[0])); HIP_OK(hipEventCreate(&s.poll_ev[1])); HIP_OK(hipEventCreate(&s.t_begin)); HIP_OK(hipEventCreate(&s.t_end)); }
-  const bool profile = (rp_in.flags & LR_FLAG_PROFILE) != 0, count = (rp_in.flags & LR_FLAG_COUNT) != 0;
+  const bool profile = (rp_in.flags & LR_FLAG_PROFILE) != 0;
   if (profile) for (auto& p : s.pools) p.init();
   for (auto& p : s.pools) p.used = 0;
 
@@ -342,7 +352,14 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_seg * kBlock);
 
   Launcher L{s, profile};
-  if (n_items > 0) {
+  if (n_items > 0 && resident) {
+    uint32_t mt_mask = 0;
+    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+    HIP_OK(hipFuncSetAttribute((const void*)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
+    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_seg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.prims.p); });
+    S.iterations = 1;
+    HIP_OK(hipStreamSynchronize(st));
+  } else if (n_items > 0) {
     L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, s.dev, ds, dp); });
     const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
     const int kCheck = 8;
@@ -355,8 +372,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds); });
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p); });
         if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp); });
@@ -364,8 +381,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask); });
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p); });
         }
         L.iter++; S.iterations++;
       }
@@ -533,7 +550,7 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
     size_t lds = (size_t)s->stack_depth * kBlock * 8;
-    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
+    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, (const float4*)s->prims.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
