@@ -189,13 +189,37 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
 template <bool SHADOW>
 LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, int n, V3 o, V3 d, float dist) {
   TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = 0;
+  // rows of primitive k+1 are requested (s_load) before primitive k is tested
+  float4 n0 = prims[0], n1 = prims[1], n2 = prims[2];
   for (int k = 0; k < n; ++k) {
-    float4 q0 = prims[3 * k], q1 = prims[3 * k + 1];
+    float4 q0 = n0, q1 = n1, q2 = n2;
+    if (k + 1 < n) { n0 = prims[3 * k + 3]; n1 = prims[3 * k + 4]; n2 = prims[3 * k + 5]; }
     uint32_t idw = __float_as_uint(q0.w);
     int id = (int)(idw & 0x7fffffffu);
-    float t; bool hit;
-    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
-    else { float4 q2 = prims[3 * k + 2]; hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t); }
+    float t = 0.0f; bool hit = false;
+    if (idw >> 31) {
+      hit = sphere_test(v3(q0), q1.y, o, d, &t);
+    } else {
+      // triangle.rs:69-100, same operations as tri_test(); the two __ballot tests only skip work
+      // that no lane of the wave needs (all lanes already rejected), they never change a result
+      V3 p0 = v3(q0), e1 = v3(q1), e2 = v3(q2);
+      V3 pv = cross(d, e2);
+      float det = dot(e1, pv);
+      bool ok = !(__builtin_fabsf(det) < kEps);
+      float invdet = 1.0f / det;
+      V3 tv = o - p0;
+      float u = dot(tv, pv) * invdet;
+      ok = ok && !(u < 0.0f || u > 1.0f);
+      if (__ballot(ok) != 0) {
+        V3 qv = cross(tv, e1);
+        float v = dot(d, qv) * invdet;
+        ok = ok && !(v < 0.0f || u + v > 1.0f);
+        if (__ballot(ok) != 0) {
+          t = dot(e2, qv) * invdet;
+          hit = ok && !(t < kEps);
+        }
+      }
+    }
     if (SHADOW) {
       float diff = t - dist;
       if (hit && diff < -kEps) res.occluded = true;
@@ -859,7 +883,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
 // (small traversal stacks); results are bit-identical to the streaming pipeline (same device
 // functions, same RNG keys, same chunk order).
 // ==========================================================================================
-LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need) {
+LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t batch) {
   uint32_t t0 = pl->taken < pl->a0 ? pl->taken : pl->a0;
   pl->r0 += t0; pl->a0 -= t0;
   uint32_t rest = pl->taken - t0;
@@ -870,8 +894,8 @@ LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need) {
   if (pl->a0 < need && pl->a1 == 0) {
     uint32_t cur = __hip_atomic_load(st.next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur < st.n_items) {
-      uint32_t nb = atomicAdd(st.next_item, (uint32_t)kSeg);
-      if (nb < st.n_items) { pl->r1 = nb; pl->a1 = st.n_items - nb < (uint32_t)kSeg ? st.n_items - nb : (uint32_t)kSeg; }
+      uint32_t nb = atomicAdd(st.next_item, batch);
+      if (nb < st.n_items) { pl->r1 = nb; pl->a1 = st.n_items - nb < batch ? st.n_items - nb : batch; }
     }
     if (pl->a0 == 0) { pl->r0 = pl->r1; pl->a0 = pl->a1; pl->a1 = 0; }
   }
@@ -898,38 +922,41 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
   }
 }
 
-constexpr int kResidentStateBytes = 7 * kSeg * 16 + kSeg * 8 + 7 * kSeg * 2;   // 68608
+constexpr int kRSeg = 256;               // slots per resident workgroup (one per thread): 34 KB of LDS, 4 workgroups per CU
+constexpr int kResidentStateBytes = 7 * kRSeg * 16 + kRSeg * 8 + 7 * kRSeg * 2;
 
-__global__ void __launch_bounds__(kBlock, 2) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+__global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
   extern __shared__ float4 lds4[];
   __shared__ PoolLds pl;
   __shared__ uint32_t s_cnt[8];            // [0..5] shade lists, [6] shadow list
   __shared__ uint32_t s_retired;
   __shared__ uint32_t s_stat[ST_COUNT];
   DevState st = gst;
-  st.ray_o = lds4; st.ray_d = lds4 + kSeg; st.thr = lds4 + 2 * kSeg; st.rad = lds4 + 3 * kSeg;
-  st.acc = lds4 + 4 * kSeg; st.sh_d = lds4 + 5 * kSeg; st.sh_w = lds4 + 6 * kSeg;
-  st.hit = (float2*)(lds4 + 7 * kSeg);
-  uint16_t* lists = (uint16_t*)(st.hit + kSeg);                     // [7][kSeg]
-  uint32_t* stk_n = (uint32_t*)(lists + 7 * kSeg);
+  st.ray_o = lds4; st.ray_d = lds4 + kRSeg; st.thr = lds4 + 2 * kRSeg; st.rad = lds4 + 3 * kRSeg;
+  st.acc = lds4 + 4 * kRSeg; st.sh_d = lds4 + 5 * kRSeg; st.sh_w = lds4 + 6 * kRSeg;
+  st.hit = (float2*)(lds4 + 7 * kRSeg);
+  uint16_t* lists = (uint16_t*)(st.hit + kRSeg);                    // [7][kRSeg]
+  uint32_t* stk_n = (uint32_t*)(lists + 7 * kRSeg);
   float* stk_t = (float*)(stk_n + (size_t)gst.stack_depth * kBlock);
+  uint16_t* shq = lists + 6 * kRSeg;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
-  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kSeg); s_retired = 0; }
+  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kRSeg, kRSeg); s_retired = 0; }
   __syncthreads();
-  for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+  for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
     bool r = finish_and_regenerate(sc, st, rp, &pl, step * kBlock + tid, false, true, v3(0, 0, 0), 1.0f, 0, 0);
     (void)wave_reserve(&s_retired, r);
   }
   uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;
   while (true) {
-    __syncthreads();
-    if (s_retired >= (uint32_t)kSeg) break;                        // wave-uniform: read after the barrier
-    __syncthreads();
+    __syncthreads();                                                // previous iteration (or generation) complete
+    const uint32_t retired = s_retired;
+    if (retired >= (uint32_t)kRSeg) break;                          // wave-uniform
     if (tid < 8) s_cnt[tid] = 0;
+    if (tid == 8) pool_step(st, &pl, (uint32_t)kRSeg - retired, kRSeg);   // at most one new item per live slot and iteration
     __syncthreads();
     // ---- phase 1: closest hit for every live slot, compaction by BSDF ----
-    for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
+    for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
       uint32_t slot = step * kBlock + tid;
       bool active = false; int qid = -1;
       float4 ro = st.ray_o[slot];
@@ -947,25 +974,18 @@ __global__ void __launch_bounds__(kBlock, 2) k_resident(DevScene sc, DevState gs
         int q = __shfl(qid, lead, 64);
         bool mine = active && qid == q;
         uint32_t idx = wave_reserve(&s_cnt[q], mine);
-        if (mine) lists[q * kSeg + idx] = (uint16_t)slot;
+        if (mine) lists[q * kRSeg + idx] = (uint16_t)slot;
         todo &= ~__ballot(mine);
       }
     }
     __syncthreads();
-    if (tid == 0) {                                                 // at most one new item per live slot this iteration
-      uint32_t need = 0;
-      for (int q = 0; q < kNumShadeQueues; ++q) need += s_cnt[q];
-      pool_step(st, &pl, need);
-    }
-    __syncthreads();
     // ---- phase 2: one BSDF-specialised body per list ----
-    uint16_t* shq = lists + 6 * kSeg;
-    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, &pl, lists + 0 * kSeg, s_cnt[0], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, &pl, lists + 1 * kSeg, s_cnt[1], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, &pl, lists + 2 * kSeg, s_cnt[2], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, &pl, lists + 3 * kSeg, s_cnt[3], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, &pl, lists + 4 * kSeg, s_cnt[4], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    resident_shade_list<kQMiss>(sc, st, rp, &pl, lists + 5 * kSeg, s_cnt[5], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, &pl, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, &pl, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, &pl, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, &pl, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, &pl, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    resident_shade_list<kQMiss>(sc, st, rp, &pl, lists + 5 * kRSeg, s_cnt[5], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
     __syncthreads();
     // ---- phase 3: shadow rays of this iteration ----
     const uint32_t nsh = s_cnt[6];

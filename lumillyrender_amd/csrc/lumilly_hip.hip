@@ -287,12 +287,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // pipeline: resident (one launch, path state in LDS) when two workgroups fit a CU's 160 KB of LDS
   const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 8;
   const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
-  bool resident = resident_lds <= 80 * 1024 && !count;
+  bool resident = resident_lds <= 40 * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
-  const int resident_per_cu = resident_lds <= 80 * 1024 ? 2 : 1;
-  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kSeg) : (1u << 20));
-  if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kSeg));   // every workgroup must be resident: no grid-stride
+  const int resident_per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (resident_lds + 512))));
+  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : (1u << 20));
+  if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -356,7 +356,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     HIP_OK(hipFuncSetAttribute((const void*)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_seg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.prims.p); });
+    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.prims.p); });
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {
