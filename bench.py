@@ -15,7 +15,7 @@ each render (host gather).  --scaling weak (default) keeps per-GPU work fixed: t
 1024*N spp, each rank owning 1/N of the pixels; --scaling strong keeps the frame at 1024 spp.
 
 The JSON line also carries
-  roofline     for the dominant kernel (k_trace): algorithmic bytes per launch / mean launch duration,
+  roofline     for the dominant kernel (k_resident, or k_trace when streaming): algorithmic bytes per launch / mean launch duration,
                the duration measured with HIP events around the launches inside the timed region
   cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) on this box's host cores,
                on a bounded sample of the same frame
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--streaming", action="store_true", help="force the multi-kernel streaming pipeline")
     return ap.parse_args()
 
 
@@ -97,7 +98,7 @@ def main():
     desc.set_resolution(W, H)
     scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
-    flags = 0 if args.no_profile else abi.LR_FLAG_PROFILE
+    flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
     canvas = np.zeros((H, W, 3), dtype=np.float32)
     barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if world > 1 else None
 
@@ -115,18 +116,16 @@ def main():
 
     for i in range(args.warmup):
         step(1000 + i)
-    acc = {"trace_ms": 0.0, "trace_timed": 0, "trace_launches": 0, "segments": 0, "shadow": 0, "samples": 0,
-           "kernel_ms": [0.0] * abi.LR_K_COUNT, "kernel_timed": [0] * abi.LR_K_COUNT, "iterations": 0, "render_ms": 0.0}
+    acc = {"segments": 0, "shadow": 0, "samples": 0, "iterations": 0, "render_ms": 0.0,
+           "kernel_ms": [0.0] * abi.LR_K_COUNT, "kernel_timed": [0] * abi.LR_K_COUNT, "kernel_launches": [0] * abi.LR_K_COUNT}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         st = step(i)
-        acc["trace_ms"] += st.kernel_ms[abi.LR_K_TRACE]; acc["trace_timed"] += st.kernel_timed[abi.LR_K_TRACE]
-        acc["trace_launches"] += st.kernel_launches[abi.LR_K_TRACE]
         acc["segments"] += st.segments; acc["shadow"] += st.shadow_rays; acc["samples"] += st.samples
         acc["iterations"] += st.iterations; acc["render_ms"] += st.render_ms
         for k in range(abi.LR_K_COUNT):
-            acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]
+            acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]; acc["kernel_launches"][k] += st.kernel_launches[k]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -149,44 +148,58 @@ def main():
                             f"{W}x{H} {spp} spp pt-direct, Lambert only",
                 "width": W, "height": H, "spp": spp, "integrator": "pt-direct", "tile": args.tile,
                 "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, host gather",
-                "path_slots": args.slots or (1 << 20),
+                "path_slots": args.slots or "library default",
             },
         }
-        # ---- roofline of the dominant kernel (k_trace), N = 1 only -------------------------------------
-        if world == 1 and acc["trace_timed"] > 0:
-            # node visits / primitive tests per segment: one short counted render (same scene, same
-            # estimator; the ratios are per-segment averages and do not depend on spp)
+        # ---- roofline of the dominant kernel, N = 1 only ---------------------------------------------
+        names = abi.LR_KERNEL_NAMES
+        dom = max(range(abi.LR_K_COUNT), key=lambda k: acc["kernel_ms"][k] / max(acc["kernel_timed"][k], 1) * acc["kernel_launches"][k])
+        if world == 1 and acc["kernel_timed"][dom] > 0:
+            # DESIGN.md "algorithmic bytes" = SURVEY 8(d) with this build's record sizes, per camera sample:
+            #   224 B per closest-hit segment (ray 32 r + hit/list 16 w in trace; 96 r + 80 w of ray, hit, throughput,
+            #   radiance in shade), 108 B per shadow ray (48 w + 48 r + 12 rw), 32 B per child box tested, 48 B per
+            #   primitive tested (1/64 of that when the primitive rows come through the scalar cache once per wave),
+            #   12 B per film pixel.  Box / primitive counts come from one short counted render (LR_FLAG_COUNT).
             pc = desc.render_params(spp=32, seed=77, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=abi.LR_FLAG_COUNT, path_slots=args.slots)
             scene.render(pc, tiles, n_tiles, out=canvas)
             sc = scene.stats()
-            v_per_seg = sc.node_visits / max(sc.segments, 1)
-            t_per_seg = sc.prim_tests / max(sc.segments, 1)
-            seg_per_launch = acc["segments"] / max(acc["trace_launches"], 1)
-            # DESIGN.md "algorithmic bytes": ray record read 32 B + hit record written 8 B + queue slot id
-            # written 4 B per segment, 32 B per child box tested, 48 B per primitive tested
-            bytes_per_seg = 32.0 + 8.0 + 4.0 + 32.0 * v_per_seg + 48.0 * t_per_seg
-            avg_ms = acc["trace_ms"] / acc["trace_timed"]
-            achieved = bytes_per_seg * seg_per_launch / (avg_ms * 1e-3) / 1e9
+            flat = desc.desc.n_prims <= 32
+            queries = max(sc.segments + sc.shadow_rays, 1)
+            v_per_q = (sc.node_visits + sc.shadow_node_visits) / queries
+            t_per_q = (sc.prim_tests + sc.shadow_prim_tests) / queries
+            s_per = acc["segments"] / acc["samples"]
+            q_per = acc["shadow"] / acc["samples"]
+            scene_bytes_per_q = 32.0 * v_per_q + 48.0 * t_per_q / (64.0 if flat else 1.0)
+            bytes_per_sample = 224.0 * s_per + 108.0 * q_per + scene_bytes_per_q * (s_per + q_per) + 12.0 / spp
+            avg_ms = acc["kernel_ms"][dom] / acc["kernel_timed"][dom]
+            if dom == abi.LR_K_RESIDENT:        # one launch renders the whole frame
+                units = float(W) * H * spp
+                bytes_per_launch = bytes_per_sample * units
+                unit_name = "camera samples"
+            else:                               # streaming pipeline: the trace kernel's own share per segment
+                units = acc["segments"] / max(acc["kernel_launches"][abi.LR_K_TRACE], 1)
+                bytes_per_launch = (32.0 + 8.0 + 4.0 + 32.0 * sc.node_visits / max(sc.segments, 1) + 48.0 * sc.prim_tests / max(sc.segments, 1) / (64.0 if flat else 1.0)) * units
+                unit_name = "segments"
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("k_trace_hbm_bytes_per_launch")
+                    traffic = json.load(open(tpath)).get(f"k_{names[dom]}_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "kernel": "k_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": f"k_{names[dom]}", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 5), "segments_per_launch": round(seg_per_launch, 1),
-                "bytes_per_segment": round(bytes_per_seg, 1), "node_boxes_per_segment": round(v_per_seg, 2),
-                "prim_tests_per_segment": round(t_per_seg, 2), "timed_launches": acc["trace_timed"],
+                "avg_launch_ms": round(avg_ms, 5), "units_per_launch": round(units, 1), "unit": "GB/s", "units": unit_name,
+                "algorithmic_bytes_per_launch": round(bytes_per_launch, 0), "bytes_per_camera_sample": round(bytes_per_sample, 1),
+                "boxes_per_query": round(v_per_q, 2), "prim_tests_per_query": round(t_per_q, 2),
+                "timed_launches": acc["kernel_timed"][dom],
             }
-            names = abi.LR_KERNEL_NAMES
             out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
                                             for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
-            out["path_stats"] = {"segments_per_sample": round(acc["segments"] / acc["samples"], 3),
-                                 "shadow_rays_per_sample": round(acc["shadow"] / acc["samples"], 3),
-                                 "iterations_per_step": acc["iterations"] // max(args.steps, 1)}
+            out["path_stats"] = {"segments_per_sample": round(s_per, 3), "shadow_rays_per_sample": round(q_per, 3),
+                                 "pipeline": "resident" if dom == abi.LR_K_RESIDENT else "streaming"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, args)
         print(json.dumps(out), flush=True)

@@ -980,7 +980,8 @@ int lr_oracle_render(const LrSceneDesc* desc, const LrRenderParams* params, cons
   std::vector<Counters> counters((size_t)n_threads);
   auto t0 = std::chrono::steady_clock::now();
   auto worker = [&](int tid) {
-    Counters* ct = stats ? &counters[(size_t)tid] : nullptr;
+    Counters local;                                   // thread-private (no false sharing); published once at the end
+    Counters* ct = stats ? &local : nullptr;
     for (;;) {
       size_t r = next.fetch_add(1);
       if (r >= rows.size()) break;
@@ -991,6 +992,7 @@ int lr_oracle_render(const LrSceneDesc* desc, const LrRenderParams* params, cons
         o[0] = px.x; o[1] = px.y; o[2] = px.z;
       }
     }
+    counters[(size_t)tid] = local;
   };
   std::vector<std::thread> th;
   for (int i = 1; i < n_threads; ++i) th.emplace_back(worker, i);
