@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--streaming", action="store_true", help="force the multi-kernel streaming pipeline")
+    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl", help="torch.distributed backend (testing: gloo)")
+    ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: every rank renders on GPU 0")
     return ap.parse_args()
 
 
@@ -87,9 +89,13 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if "nccl" in args.backend:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     dev_index = local_rank if world > 1 else 0
 
     W, H = args.width, args.height
@@ -100,7 +106,9 @@ def main():
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
     flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
     canvas = np.zeros((H, W, 3), dtype=np.float32)
-    barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if world > 1 else None
+    barrier_buf = None
+    if world > 1:
+        barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if "nccl" in args.backend else torch.zeros(1)
 
     def barrier():
         if dist is not None:

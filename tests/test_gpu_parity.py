@@ -334,3 +334,51 @@ def test_full_size_properties(dev):
     b = s2.render(params)
     assert np.array_equal(b, a * np.float32(2.0))
     s2.close()
+
+
+@pytest.mark.parametrize("name,integ", [("cbox-spheres.toml", 1), ("cbox-spheres.toml", 0), ("brdf-row.toml", 1), ("two-spheres.toml", None)])
+def test_resident_and_streaming_pipelines_are_bit_identical(dev, oracle, name, integ):
+    """The single-launch resident pipeline (path state in LDS) and the multi-kernel streaming pipeline
+    (path state in HBM) run the same device functions with the same RNG keys and chunk order: same film,
+    same path statistics, and both within tolerance of the oracle."""
+    from lumillyrender_amd import abi
+    desc = load(name, 56, 40)
+    scene = dev.Scene(desc)
+    films, stats = [], []
+    for flags in (abi.LR_FLAG_RESIDENT, abi.LR_FLAG_STREAMING, abi.LR_FLAG_STREAMING | abi.LR_FLAG_COUNT):
+        p = desc.render_params(spp=24, seed=13, integrator=integ, flags=flags)
+        films.append(scene.render(p))
+        st = scene.stats()
+        stats.append((st.samples, st.segments, st.shadow_rays, st.kernel_launches[abi.LR_K_RESIDENT]))
+    assert stats[0][3] == 1 and stats[1][3] == 0            # the flags really selected the two pipelines
+    assert stats[0][:3] == stats[1][:3] == stats[2][:3]
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[1], films[2])
+    ref = oracle.render(desc, desc.render_params(spp=24, seed=13, integrator=integ))
+    assert linf(films[0], ref) < TOL
+    scene.close()
+
+
+def test_bvh_path_on_a_small_scene(dev, oracle):
+    """Scenes with more than 32 primitives walk the tree (LDS traversal stack); 60 spheres keep the oracle's
+    brute force fast enough to compare images in both pipelines."""
+    from lumillyrender_amd import abi
+    rng = np.random.default_rng(12)
+    objs = []
+    for i in range(60):
+        c = rng.random(3) * [400, 300, 400] + [80, 40, 80]
+        objs.append(f'[[object]]\nmesh = "ball"\nmaterial = "{"matte" if i % 3 else "shiny"}"\ntransform = [ {{ type = "translate", vector = [{c[0]:.3f}, {c[1]:.3f}, {c[2]:.3f}] }} ]\n')
+
+    def edit(t):
+        t = t.replace('radius = 100 }', 'radius = 22 }')
+        t = t.replace('  { name = "dark",', '  { name = "shiny", type = "ggx", reflectance = [0.9, 0.9, 0.9], roughness = 0.5, ior = 100000 },\n  { name = "dark",')
+        return t + "\n" + "\n".join(objs)
+    desc = load("cbox-spheres.toml", 40, 32, text_edit=edit)
+    assert desc.desc.n_prims == 14 + 60
+    scene = dev.Scene(desc)
+    ref, ost = oracle.render(desc, desc.render_params(spp=12, seed=6), with_stats=True)
+    for flags in (0, abi.LR_FLAG_STREAMING, abi.LR_FLAG_RESIDENT):
+        img = scene.render(desc.render_params(spp=12, seed=6, flags=flags))
+        st = scene.stats()
+        assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
+        assert linf(img, ref) < TOL
+    scene.close()
