@@ -259,6 +259,14 @@ LR_DEV V3 orienting_normal(V3 out_, V3 normal) {                       // lamber
 // materials.  Mat = the three float4 rows of the material table.
 // ------------------------------------------------------------------------------------------
 struct Mat { float4 m0, m1, m2; };
+
+// Radiance-only arithmetic.  BSDF values, pdfs, throughput and radiance never feed a decision (hit / miss,
+// Russian roulette, light pick, ray directions): they only scale what is added to the film, and the
+// parity bar on the film is 1e-4, not bit equality.  So their divisions use v_rcp_f32 (1 ulp) instead of
+// the ten-instruction IEEE sequence.  Everything that builds a ray, a hit or a branch stays exact.
+constexpr float kInvPi = 0.318309886183790671537767526745028724f;
+LR_DEV float rcp_r(float x) { return __builtin_amdgcn_rcpf(x); }
+LR_DEV V3 div_r(V3 a, float s) { float r = __builtin_amdgcn_rcpf(s); return v3(a.x * r, a.y * r, a.z * r); }
 LR_DEV V3 mcolor(const Mat& m) { return v3(m.m0); }
 
 LR_DEV float signed_mod(float base, float module) {                    // lambert.rs:58-64
@@ -310,8 +318,8 @@ LR_DEV float fresnel_exact(float n1, float n2, V3 out_, V3 in_, V3 on) {        
 template <int MT>
 LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
   if (MT == LR_MAT_LAMBERT) {                                          // lambert.rs:32-35
-    float g = checker(pos.x, pos.z);
-    return mcolor(m) * v3(g, g, g) / kPi;
+    float g = checker(pos.x, pos.z) * kInvPi;
+    return mcolor(m) * g;
   } else if (MT == LR_MAT_PHONG) {                                     // phong.rs:37-45
     V3 on = orienting_normal(out_, n);
     if (dot(in_, on) <= 0.0f) return v3(0, 0, 0);
@@ -334,7 +342,7 @@ LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
     float f = ggx_fresnel(m.m2.y, in_, h);
     float g = ggx_g(alpha, in_, on) * ggx_g(alpha, out_, on);
     float d = ggx_ndf(alpha, h, on);
-    return mcolor(m) * f * g * d / (4.0f * dot(in_, on) * dot(out_, on));
+    return div_r(mcolor(m) * f * g * d, 4.0f * dot(in_, on) * dot(out_, on));
   } else {                                                             // ideal_refraction.rs:39-66
     V3 on = orienting_normal(out_, n);
     float from_ior, to_ior; ior_pair(m.m2.x, out_, n, &from_ior, &to_ior);
@@ -362,7 +370,7 @@ LR_DEV void material_sample(const Mat& m, V3 out_, V3 n, const float* xi, V3* in
     float s1, c1; det_sincos(r1, &s1, &c1);
     V3 s = v3(c1 * r2s, s1 * r2s, __builtin_sqrtf(1.0f - r2));
     V3 in_ = u * s.x + v * s.y + w * s.z;
-    *in_out = in_; *pdf_out = dot(in_, n) / kPi;
+    *in_out = in_; *pdf_out = dot(in_, n) * kInvPi;
   } else if (MT == LR_MAT_PHONG) {                                     // phong.rs:47-68
     V3 on = orienting_normal(out_, n);
     float a = m.m2.x;
@@ -403,7 +411,7 @@ LR_DEV void material_sample(const Mat& m, V3 out_, V3 n, const float* xi, V3* in
     V3 h = u * c1 * s + v * s1 * s + w * c;
     float o_h = dot(out_, h);
     V3 in_ = h * (2.0f * o_h) - out_;
-    float jacobian = 1.0f / (4.0f * o_h);
+    float jacobian = rcp_r(4.0f * o_h);
     *in_out = in_; *pdf_out = ggx_ndf(alpha, h, on) * dot(h, on) * jacobian;
   } else {                                                             // ideal_refraction.rs:68-104
     float from_ior, to_ior; ior_pair(m.m2.x, out_, n, &from_ior, &to_ior);
@@ -747,7 +755,7 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
         float point_cos = dot(dir, point_normal);
         if (point_cos > 0.0f) {
           V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
-          V3 W = T * (brdf * (point_cos / d2) / lpdf / p);
+          V3 W = T * (brdf * (point_cos * rcp_r(d2 * lpdf * p)));
           st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
           st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
           out.has_shadow = true;
@@ -760,7 +768,7 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
       V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
       V3 coef = material_coef<MT>(m, out_, nrm, t);
       float c = dot(in_, nrm);
-      V3 f = brdf * coef * c / pdf / p;
+      V3 f = brdf * coef * (c * rcp_r(pdf * p));
       T = T * f;
       st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
       st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, out.g_term);
@@ -948,13 +956,21 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
     (void)wave_reserve(&s_retired, r);
   }
   uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;
+#ifdef LR_STAMP
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#define LR_TICK(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tk[i] += t_now - t_prev; t_prev = t_now; }
+#else
+#define LR_TICK(i)
+#endif
   while (true) {
     __syncthreads();                                                // previous iteration (or generation) complete
+    LR_TICK(0)
     const uint32_t retired = s_retired;
     if (retired >= (uint32_t)kRSeg) break;                          // wave-uniform
     if (tid < 8) s_cnt[tid] = 0;
     if (tid == 8) pool_step(st, &pl, (uint32_t)kRSeg - retired, kRSeg);   // at most one new item per live slot and iteration
     __syncthreads();
+    LR_TICK(1)
     // ---- phase 1: closest hit for every live slot, compaction by BSDF ----
     for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
       uint32_t slot = step * kBlock + tid;
@@ -968,6 +984,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
         qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
         n_seg += 1;
       }
+      // a ray that left the scene is finished right here (sky lookup, fold, next camera sample): the
+      // miss list of the streaming pipeline would cost this workgroup a whole extra phase for ~15 % of its lanes
+      {
+        bool miss = active && qid == kQMiss;
+        VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
+        if (miss) v = shade_vertex<kQMiss>(sc, st, rp, slot);
+        if (v.finished) n_done += 1;
+        if (v.sky_fetch) n_sky += 1;
+        bool rr = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample);
+        (void)wave_reserve(&s_retired, rr);
+        if (miss) active = false;
+      }
       uint64_t todo = __ballot(active);
       while (todo) {
         int lead = (int)__builtin_ctzll(todo);
@@ -978,15 +1006,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
         todo &= ~__ballot(mine);
       }
     }
+    LR_TICK(2)
     __syncthreads();
+    LR_TICK(0)
     // ---- phase 2: one BSDF-specialised body per list ----
     if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, &pl, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
     if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, &pl, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
     if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, &pl, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
     if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, &pl, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
     if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, &pl, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
-    resident_shade_list<kQMiss>(sc, st, rp, &pl, lists + 5 * kRSeg, s_cnt[5], shq, &s_cnt[6], &s_retired, &n_done, &n_sky);
+    LR_TICK(3)
     __syncthreads();
+    LR_TICK(0)
     // ---- phase 3: shadow rays of this iteration ----
     const uint32_t nsh = s_cnt[6];
     for (uint32_t i = tid; i < nsh; i += kBlock) {
@@ -998,7 +1029,12 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
       n_shq += 1;
       shadow_resolve(sc, st, slot, o, dir, r);
     }
+    LR_TICK(4)
   }
+#ifdef LR_STAMP
+  // diagnostic build only: lane 0 of every wave adds its cycle shares to the tail of the stats buffer
+  if (lane_id() == 0) for (int i = 0; i < 5; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
+#endif
   stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
   stat_accumulate(&s_stat[ST_SHADOW], n_shq);
   stat_accumulate(&s_stat[ST_SAMPLES], n_done);

@@ -190,8 +190,11 @@ LR_DEV float det_exp(float x) {
 }
 // exact f32 remainder for x >= 0, k > 0 (Rust `%`)
 LR_DEV float det_fmod_pos(float x, float k) {
-  if (!(x < 3.0e7f)) return __builtin_fmodf(x, k);
-  float q = __builtin_floorf(x / k);
+  // exact x mod k for 0 <= x < 2^24 and integer-valued k (150, 30, 300, 1 on this path): the quotient
+  // estimate may be off by one (it uses a rounded reciprocal), x - q*k is exact either way, and the two
+  // fix-ups land on the true remainder, which is always representable.
+  if (!(x < 16777216.0f)) return __builtin_fmodf(x, k);
+  float q = __builtin_floorf(x * (1.0f / k));
   float r = x - q * k;
   if (r < 0.0f) r = r + k;
   if (r >= k) r = r - k;

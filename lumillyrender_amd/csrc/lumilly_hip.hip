@@ -304,7 +304,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.q_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
   s.pool.ensure(n_seg);
   s.counters.ensure(4);
-  s.stats_dev.ensure((size_t)kStatShards * kStatStride);
+  s.stats_dev.ensure((size_t)kStatShards * kStatStride + 8);
   s.partial.ensure(n_items);
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
@@ -334,7 +334,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload;
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
-  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), st));
+  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
   const size_t lds = (size_t)s.stack_depth * kBlock * 8;
@@ -407,6 +407,15 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
   HIP_OK(hipMemcpyAsync(hshards, s.stats_dev.p, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+#ifdef LR_STAMP
+  {
+    unsigned long long tk[8];
+    HIP_OK(hipMemcpy(tk, s.stats_dev.p + (size_t)kStatShards * kStatStride, sizeof(tk), hipMemcpyDeviceToHost));
+    double tot = 0; for (int i = 0; i < 5; ++i) tot += (double)tk[i];
+    std::fprintf(stderr, "[LR_STAMP] wave-cycle shares: barrier-wait %.1f%%  pool/zero %.1f%%  trace %.1f%%  shade %.1f%%  shadow %.1f%%\n",
+                 100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot);
+  }
+#endif
   unsigned long long hstats[ST_COUNT] = {0};
   for (int sh = 0; sh < kStatShards; ++sh) for (int k = 0; k < ST_COUNT; ++k) hstats[k] += hshards[sh * kStatStride + k];
   float ms = 0.0f; HIP_OK(hipEventElapsedTime(&ms, s.t_begin, s.t_end));
