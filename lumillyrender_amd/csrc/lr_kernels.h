@@ -95,11 +95,25 @@ LR_DEV bool sphere_test(V3 c, float r2, V3 o, V3 d, float* t_out) {
 // ------------------------------------------------------------------------------------------
 struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; };
 
+// Traversal state of one ray.  trav_step() handles exactly one node (two child boxes) or one leaf and
+// then picks the next subtree, so a kernel can interleave rays of very different depth in one wave
+// (dynamic ray fetch, see k_trace) instead of idling until the deepest ray of the wave is done.
 template <bool SHADOW>
-LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t* stk_n, float* stk_t) {
-  TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = 0;
-  float cull = SHADOW ? dist + 2.0f * kEps : 3.0e38f;       // box-pruning bound
+struct Trav {
+  V3 o, d;
   float ix, iy, iz, ox, oy, oz;
+  float cull, dist, t;
+  int prim, cur, sp;
+  bool occluded;
+  uint32_t visits, tests;
+};
+
+template <bool SHADOW>
+LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
+  s.o = o; s.d = d; s.dist = dist;
+  s.t = 3.0e38f; s.prim = -1; s.occluded = false; s.visits = 0; s.tests = 0;
+  s.cull = SHADOW ? dist + 2.0f * kEps : 3.0e38f;             // box-pruning bound
+  s.cur = 0; s.sp = 0;
   {
 #pragma clang fp contract(fast)
     // a zero direction component would give inf * 0 = NaN below, and a NaN beside an inf makes the
@@ -108,76 +122,80 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
     float dx = __builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x;
     float dy = __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y;
     float dz = __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z;
-    ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz);
-    ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+    s.ix = __builtin_amdgcn_rcpf(dx); s.iy = __builtin_amdgcn_rcpf(dy); s.iz = __builtin_amdgcn_rcpf(dz);
+    s.ox = -o.x * s.ix; s.oy = -o.y * s.iy; s.oz = -o.z * s.iz;
   }
+}
+
+// returns false when the ray is finished (result in s.t / s.prim / s.occluded)
+template <bool SHADOW>
+LR_DEV bool trav_step(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, float* stk_t) {
   const uint32_t tid = threadIdx.x;
-  int cur = 0, sp = 0;
-  while (true) {
-    if (cur >= 0) {
-      const float4* n = sc.nodes + 4 * (size_t)cur;
-      float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
-      res.visits += 2;
-      float lmin, lmax, rmin, rmax;
-      {
+  if (s.cur >= 0) {
+    const float4* n = sc.nodes + 4 * (size_t)s.cur;
+    float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
+    s.visits += 2;
+    float lmin, lmax, rmin, rmax;
+    {
 #pragma clang fp contract(fast)
-        float a0 = __builtin_fmaf(nx.x, ix, ox), a1 = __builtin_fmaf(nx.y, ix, ox);
-        float b0 = __builtin_fmaf(ny.x, iy, oy), b1 = __builtin_fmaf(ny.y, iy, oy);
-        float c0 = __builtin_fmaf(nz.x, iz, oz), c1 = __builtin_fmaf(nz.y, iz, oz);
-        lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
-        lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), cull));
-        float d0 = __builtin_fmaf(nx.z, ix, ox), d1 = __builtin_fmaf(nx.w, ix, ox);
-        float e0 = __builtin_fmaf(ny.z, iy, oy), e1 = __builtin_fmaf(ny.w, iy, oy);
-        float f0 = __builtin_fmaf(nz.z, iz, oz), f1 = __builtin_fmaf(nz.w, iz, oz);
-        rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
-        rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), cull));
-      }
-      bool hl = lmin <= lmax, hr = rmin <= rmax;
-      int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
-      if (hl && hr) {
-        bool swap = rmin < lmin;
-        int nearc = swap ? cr : cl, farc = swap ? cl : cr;
-        float fart = swap ? lmin : rmin;
-        stk_n[sp * kBlock + tid] = (uint32_t)farc;
-        stk_t[sp * kBlock + tid] = fart;
-        ++sp;
-        cur = nearc;
-        continue;
-      } else if (hl) { cur = cl; continue; }
-      else if (hr) { cur = cr; continue; }
-    } else {
-      uint32_t enc = (uint32_t)~cur;
-      uint32_t first = enc >> 3, count = enc & 7u;
-      for (uint32_t k = 0; k < count; ++k) {
-        const float4* q = sc.prims + 3 * (size_t)(first + k);
-        float4 q0 = q[0], q1 = q[1];
-        uint32_t idw = __float_as_uint(q0.w);
-        int id = (int)(idw & 0x7fffffffu);
-        float t; bool hit;
-        res.tests += 1;
-        if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
-        else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t); }
-        if (!hit) continue;
-        if (SHADOW) {
-          float diff = t - dist;
-          if (diff < -kEps) { res.occluded = true; return res; }
-          if (diff > kEps) continue;
-        }
-        if (t < res.t || (t == res.t && id < res.prim)) {
-          res.t = t; res.prim = id;
-          cull = t;
-        }
-      }
+      float a0 = __builtin_fmaf(nx.x, s.ix, s.ox), a1 = __builtin_fmaf(nx.y, s.ix, s.ox);
+      float b0 = __builtin_fmaf(ny.x, s.iy, s.oy), b1 = __builtin_fmaf(ny.y, s.iy, s.oy);
+      float c0 = __builtin_fmaf(nz.x, s.iz, s.oz), c1 = __builtin_fmaf(nz.y, s.iz, s.oz);
+      lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
+      lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull));
+      float d0 = __builtin_fmaf(nx.z, s.ix, s.ox), d1 = __builtin_fmaf(nx.w, s.ix, s.ox);
+      float e0 = __builtin_fmaf(ny.z, s.iy, s.oy), e1 = __builtin_fmaf(ny.w, s.iy, s.oy);
+      float f0 = __builtin_fmaf(nz.z, s.iz, s.oz), f1 = __builtin_fmaf(nz.w, s.iz, s.oz);
+      rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
+      rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), s.cull));
     }
-    // pop the next subtree that can still contain a closer hit
-    bool found = false;
-    while (sp > 0) {
-      --sp;
-      float pt = stk_t[sp * kBlock + tid];
-      if (pt <= cull) { cur = (int)stk_n[sp * kBlock + tid]; found = true; break; }
+    bool hl = lmin <= lmax, hr = rmin <= rmax;
+    int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
+    if (hl && hr) {
+      bool swap = rmin < lmin;
+      int nearc = swap ? cr : cl, farc = swap ? cl : cr;
+      float fart = swap ? lmin : rmin;
+      stk_n[s.sp * kBlock + tid] = (uint32_t)farc;
+      (void)fart; (void)stk_t;
+      ++s.sp;
+      s.cur = nearc;
+      return true;
+    } else if (hl) { s.cur = cl; return true; }
+    else if (hr) { s.cur = cr; return true; }
+  } else {
+    uint32_t enc = (uint32_t)~s.cur;
+    uint32_t first = enc >> 3, count = enc & 7u;
+    for (uint32_t k = 0; k < count; ++k) {
+      const float4* q = sc.prims + 3 * (size_t)(first + k);
+      float4 q0 = q[0], q1 = q[1];
+      uint32_t idw = __float_as_uint(q0.w);
+      int id = (int)(idw & 0x7fffffffu);
+      float t; bool hit;
+      s.tests += 1;
+      if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
+      else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t); }
+      if (!hit) continue;
+      if (SHADOW) {
+        float diff = t - s.dist;
+        if (diff < -kEps) { s.occluded = true; return false; }
+        if (diff > kEps) continue;
+      }
+      if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; s.cull = t; }
     }
-    if (!found) break;
   }
+  // pop the next subtree that can still contain a closer hit
+  // (entries carry no entry distance: a stale subtree costs one node fetch whose boxes then fail the
+  //  cull test, but 4 B per entry instead of 8 doubles the workgroups an LDS-bound CU can hold)
+  if (s.sp > 0) { --s.sp; s.cur = (int)stk_n[s.sp * kBlock + tid]; return true; }
+  return false;
+}
+
+template <bool SHADOW>
+LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t* stk_n, float* stk_t) {
+  Trav<SHADOW> s;
+  trav_begin<SHADOW>(s, o, d, dist);
+  while (trav_step<SHADOW>(sc, s, stk_n, stk_t)) {}
+  TraceResult res; res.t = s.t; res.prim = s.prim; res.occluded = s.occluded; res.visits = s.visits; res.tests = s.tests;
   return res;
 }
 
@@ -657,48 +675,110 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
   }
 }
 
+// Closest-hit stage of the streaming pipeline.  A workgroup owns `spb` consecutive segments (spb * 512
+// path slots) per pass and hands them to its waves through an LDS dispenser:
+//   * tree scenes: persistent while-while traversal with DYNAMIC RAY FETCH -- a lane whose ray is done
+//     writes its hit, appends its slot to the (segment, BSDF) list and draws the next slot, as soon as
+//     fewer than kRefillBelow lanes of the wave are still walking.  Ray depths differ by 10x in one
+//     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use.
+//   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
+constexpr int kMaxGroup = 8;             // segments a workgroup may own at once
+constexpr int kRefillBelow = 44;         // refill the wave when at most this many lanes are still traversing
+
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims) {
+__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint32_t s_cnt[8];
+  __shared__ uint32_t s_cnt[kMaxGroup * 8];
+  __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
   float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
-  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
-  uint32_t n_seg = 0, n_vis = 0, n_tst = 0;
-  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  const uint32_t tid = threadIdx.x;
+  if (tid < ST_COUNT) s_stat[tid] = 0;
+  uint32_t n_rays = 0, n_vis = 0, n_tst = 0;
+  for (uint32_t seg0 = blockIdx.x * spb; seg0 < st.n_seg; seg0 += gridDim.x * spb) {
+    const uint32_t nsegs = st.n_seg - seg0 < spb ? st.n_seg - seg0 : spb;
+    const uint32_t total = nsegs * kSeg, slot0 = seg0 * kSeg;
+    if (tid < kMaxGroup * 8) s_cnt[tid] = 0;
+    if (tid == 0) s_next = 0;
     __syncthreads();
-    for (uint32_t step = 0; step < kSeg / kBlock; ++step) {
-      uint32_t slot = seg * kSeg + step * kBlock + threadIdx.x;
-      bool active = false;
-      int qid = -1;
-      float4 ro = st.ray_o[slot];
-      if (__float_as_int(ro.w) >= 0) {
-        float4 rd = st.ray_d[slot];
-        active = true;
-        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
-        st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
-        qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
-        n_seg += 1;
-        if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
+    if (sc.n_flat > 0) {
+      for (uint32_t base = 0; base < total; base += kBlock) {
+        uint32_t slot = slot0 + base + tid;
+        bool active = false; int qid = -1;
+        float4 ro = st.ray_o[slot];
+        if (__float_as_int(ro.w) >= 0) {
+          float4 rd = st.ray_d[slot];
+          active = true;
+          TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
+          st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
+          qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
+          n_rays += 1;
+          if (COUNT) n_tst += r.tests;
+        }
+        uint32_t sg = base / kSeg;                                  // wave-uniform
+        uint64_t todo = __ballot(active);
+        while (todo) {
+          int lead = (int)__builtin_ctzll(todo);
+          int q = __shfl(qid, lead, 64);
+          bool mine = active && qid == q;
+          uint32_t idx = wave_reserve(&s_cnt[sg * 8 + q], mine);
+          if (mine) st.q_shade[((size_t)q * st.n_seg + seg0 + sg) * kSeg + idx] = slot;
+          todo &= ~__ballot(mine);
+        }
       }
-      // compaction: one list per BSDF (and one for misses) per segment, order-preserving within the wave
-      uint64_t todo = __ballot(active);
-      while (todo) {
-        int lead = (int)__builtin_ctzll(todo);
-        int q = __shfl(qid, lead, 64);
-        bool mine = active && qid == q;
-        uint32_t idx = wave_reserve(&s_cnt[q], mine);
-        if (mine) st.q_shade[((size_t)q * st.n_seg + seg) * kSeg + idx] = slot;
-        todo &= ~__ballot(mine);
+    } else {
+      Trav<false> tr;
+      bool has = false, fin = false;
+      uint32_t slot = 0;
+      while (true) {
+        // ---- converged point: retire finished rays (hit record + compaction into the (segment, BSDF) lists) ----
+        {
+          bool f = has && fin;
+          int key = -1;
+          if (f) {
+            st.hit[slot] = make_float2(tr.t, __int_as_float(tr.prim));
+            int qid = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
+            key = (int)((slot - slot0) / kSeg) * 8 + qid;
+            if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
+          }
+          uint64_t todo = __ballot(f);
+          while (todo) {
+            int lead = (int)__builtin_ctzll(todo);
+            int k = __shfl(key, lead, 64);
+            bool mine = f && key == k;
+            uint32_t idx = wave_reserve(&s_cnt[k], mine);
+            if (mine) st.q_shade[((size_t)(k & 7) * st.n_seg + seg0 + (uint32_t)(k >> 3)) * kSeg + idx] = slot;
+            todo &= ~__ballot(mine);
+          }
+          if (f) { has = false; fin = false; }
+        }
+        // ---- dynamic fetch: free lanes draw the next slots of this workgroup's range ----
+        bool need = !has;
+        uint32_t idx = wave_reserve(&s_next, need);
+        bool exhausted = __ballot(need && idx >= total) != 0;       // the dispenser is monotonic: one lane past the end = empty for all
+        if (need && idx < total) {
+          slot = slot0 + idx;
+          float4 ro = st.ray_o[slot];
+          if (__float_as_int(ro.w) >= 0) {
+            float4 rd = st.ray_d[slot];
+            trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
+            has = true; n_rays += 1;
+          }
+        }
+        if (__ballot(has) == 0) { if (exhausted) break; continue; }
+        // ---- walk until the wave thins out (or, with nothing left to fetch, until it is done) ----
+        const int thresh = exhausted ? 0 : kRefillBelow;
+        do {
+          if (has && !fin) { if (!trav_step<false>(sc, tr, stk_n, stk_t)) fin = true; }
+        } while (__builtin_popcountll(__ballot(has && !fin)) > thresh);
       }
     }
     __syncthreads();
-    if (threadIdx.x < kNumShadeQueues) st.c_shade[threadIdx.x * st.n_seg + seg] = s_cnt[threadIdx.x];
+    if (tid < nsegs * 8 && (tid & 7) < kNumShadeQueues) st.c_shade[(tid & 7) * st.n_seg + seg0 + (tid >> 3)] = s_cnt[tid];
     __syncthreads();
   }
-  stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
+  stat_accumulate(&s_stat[ST_SEGMENTS], n_rays);
   if (COUNT) { stat_accumulate(&s_stat[ST_NODE_VISITS], n_vis); stat_accumulate(&s_stat[ST_PRIM_TESTS], n_tst); }
   __syncthreads();
   stat_flush(st.stats, s_stat);
@@ -840,38 +920,77 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   stat_flush(st.stats, s_stat);
 }
 
-// mt_mask: BSDF types present in the scene (their k_shade wrote this iteration's shadow lists)
+// Shadow stage of the streaming pipeline (scene.rs:127-147).  mt_mask = BSDF types present in the scene
+// (their k_shade wrote this iteration's shadow lists).  Same workgroup ranges and the same dynamic ray
+// fetch as k_trace; the work list is the concatenation of the (segment, BSDF) shadow lists of the range.
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint32_t s_pref[kNumShadeQueues];
+  __shared__ uint32_t s_pref[kMaxGroup * 8 + 1];                   // prefix over (segment, BSDF) sub-lists
+  __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
   float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
-  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
+  const uint32_t tid = threadIdx.x;
+  if (tid < ST_COUNT) s_stat[tid] = 0;
   uint32_t n_q = 0, n_vis = 0, n_tst = 0;
-  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-    if (threadIdx.x == 0) {
+  for (uint32_t seg0 = blockIdx.x * spb; seg0 < st.n_seg; seg0 += gridDim.x * spb) {
+    const uint32_t nsegs = st.n_seg - seg0 < spb ? st.n_seg - seg0 : spb;
+    __syncthreads();
+    if (tid == 0) {
       uint32_t acc = 0;
-      for (int k = 0; k < kNumShadeQueues - 1; ++k) { s_pref[k] = acc; if (mt_mask & (1u << k)) acc += st.c_shadow[k * st.n_seg + seg]; }
-      s_pref[kNumShadeQueues - 1] = acc;
+      for (uint32_t sg = 0; sg < nsegs; ++sg)
+        for (int k = 0; k < 8; ++k) {
+          s_pref[sg * 8 + k] = acc;
+          if (k < kNumShadeQueues - 1 && (mt_mask & (1u << k))) acc += st.c_shadow[k * st.n_seg + seg0 + sg];
+        }
+      s_pref[nsegs * 8] = acc;
+      s_next = 0;
     }
     __syncthreads();
-    const uint32_t n = s_pref[kNumShadeQueues - 1];
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-      int k = 0;
-      while (k < kNumShadeQueues - 2 && i >= s_pref[k + 1]) ++k;
-      uint32_t slot = st.q_shadow[((size_t)k * st.n_seg + seg) * kSeg + (i - s_pref[k])];
-      // NOTE: shade already advanced ray_o to the hit point, which is the shadow ray origin (scene.rs:114-117)
-      float4 ro = st.ray_o[slot];
-      float4 sd = st.sh_d[slot];
-      V3 o = v3(ro), dir = v3(sd);
-      TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
-      n_q += 1;
-      if (COUNT) { n_vis += r.visits; n_tst += r.tests; }
-      shadow_resolve(sc, st, slot, o, dir, r);
+    const uint32_t total = s_pref[nsegs * 8], nsub = nsegs * 8;
+    auto entry_slot = [&](uint32_t i) -> uint32_t {                 // i-th shadow ray of the range -> slot id
+      uint32_t lo = 0, hi = nsub - 1;
+      while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= i) lo = mid; else hi = mid - 1; }
+      return st.q_shadow[((size_t)(lo & 7) * st.n_seg + seg0 + (lo >> 3)) * kSeg + (i - s_pref[lo])];
+    };
+    if (sc.n_flat > 0) {
+      for (uint32_t i = tid; i < total; i += kBlock) {
+        uint32_t slot = entry_slot(i);
+        float4 ro = st.ray_o[slot], sd = st.sh_d[slot];             // shade advanced ray_o to the hit point = shadow origin (scene.rs:114-117)
+        V3 o = v3(ro), dir = v3(sd);
+        TraceResult r = traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w);
+        n_q += 1;
+        if (COUNT) n_tst += r.tests;
+        shadow_resolve(sc, st, slot, o, dir, r);
+      }
+    } else {
+      Trav<true> tr;
+      bool has = false, fin = false;
+      uint32_t slot = 0;
+      while (true) {
+        if (has && fin) {
+          TraceResult r; r.t = tr.t; r.prim = tr.prim; r.occluded = tr.occluded; r.visits = tr.visits; r.tests = tr.tests;
+          if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
+          shadow_resolve(sc, st, slot, tr.o, tr.d, r);
+          has = false; fin = false;
+        }
+        bool need = !has;
+        uint32_t idx = wave_reserve(&s_next, need);
+        bool exhausted = __ballot(need && idx >= total) != 0;
+        if (need && idx < total) {
+          slot = entry_slot(idx);
+          float4 ro = st.ray_o[slot], sd = st.sh_d[slot];
+          trav_begin<true>(tr, v3(ro), v3(sd), sd.w);
+          has = true; n_q += 1;
+        }
+        if (__ballot(has) == 0) break;                              // every drawn entry is a ray: empty wave = list exhausted
+        const int thresh = exhausted ? 0 : kRefillBelow;
+        do {
+          if (has && !fin) { if (!trav_step<true>(sc, tr, stk_n, stk_t)) fin = true; }
+        } while (__builtin_popcountll(__ballot(has && !fin)) > thresh);
+      }
     }
-    __syncthreads();
   }
   stat_accumulate(&s_stat[ST_SHADOW], n_q);
   if (COUNT) { stat_accumulate(&s_stat[ST_SHADOW_VISITS], n_vis); stat_accumulate(&s_stat[ST_SHADOW_TESTS], n_tst); }

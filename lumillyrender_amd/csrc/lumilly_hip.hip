@@ -285,7 +285,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t n_items = (uint32_t)n_items64;
   const bool count = (rp_in.flags & LR_FLAG_COUNT) != 0;
   // pipeline: resident (one launch, path state in LDS) when two workgroups fit a CU's 160 KB of LDS
-  const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 8;
+  const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 4;
   const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
   bool resident = resident_lds <= 40 * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
@@ -337,11 +337,13 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
-  const size_t lds = (size_t)s.stack_depth * kBlock * 8;
+  const size_t lds = (size_t)s.stack_depth * kBlock * 4;
   const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
   const void* kshadow = count ? (const void*)k_shadow<true> : (const void*)k_shadow<false>;
   const int g_trace = grid_for(ktrace, s.n_cus, lds, n_seg * kBlock);
   const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
+  const uint32_t spb_trace = std::min<uint32_t>(kMaxGroup, (n_seg + g_trace - 1) / g_trace);     // segments per workgroup pass
+  const uint32_t spb_shadow = std::min<uint32_t>(kMaxGroup, (n_seg + g_shadow - 1) / g_shadow);
   const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_seg * kBlock);
   int g_shade[kNumShadeQueues];
   g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_seg * kBlock);
@@ -372,8 +374,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p); });
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p, spb_trace); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p, spb_trace); });
         if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp); });
@@ -381,8 +383,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p); });
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p, spb_shadow); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p, spb_shadow); });
         }
         L.iter++; S.iterations++;
       }
@@ -558,7 +560,7 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
-    size_t lds = (size_t)s->stack_depth * kBlock * 8;
+    size_t lds = (size_t)s->stack_depth * kBlock * 4;
     if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, (const float4*)s->prims.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
