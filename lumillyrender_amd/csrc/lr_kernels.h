@@ -95,8 +95,8 @@ LR_DEV bool sphere_test(V3 c, float r2, V3 o, V3 d, float* t_out) {
 // ------------------------------------------------------------------------------------------
 struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; };
 
-// Traversal state of one ray.  trav_step() handles exactly one node (two child boxes) or one leaf and
-// then picks the next subtree, so a kernel can interleave rays of very different depth in one wave
+// Traversal state of one ray.  trav_node() / trav_leaf() advance it by one inner node or one leaf, so a
+// kernel can interleave rays of very different depth in one wave
 // (dynamic ray fetch, see k_trace) instead of idling until the deepest ray of the wave is done.
 template <bool SHADOW>
 struct Trav {
@@ -127,74 +127,98 @@ LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
   }
 }
 
-// returns false when the ray is finished (result in s.t / s.prim / s.occluded)
+// (stack entries carry no entry distance: a stale subtree costs one node fetch whose boxes then fail
+//  the cull test, but 4 B per entry instead of 8 doubles the workgroups an LDS-bound CU can hold)
 template <bool SHADOW>
-LR_DEV bool trav_step(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, float* stk_t) {
-  const uint32_t tid = threadIdx.x;
-  if (s.cur >= 0) {
-    const float4* n = sc.nodes + 4 * (size_t)s.cur;
-    float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
-    s.visits += 2;
-    float lmin, lmax, rmin, rmax;
-    {
-#pragma clang fp contract(fast)
-      float a0 = __builtin_fmaf(nx.x, s.ix, s.ox), a1 = __builtin_fmaf(nx.y, s.ix, s.ox);
-      float b0 = __builtin_fmaf(ny.x, s.iy, s.oy), b1 = __builtin_fmaf(ny.y, s.iy, s.oy);
-      float c0 = __builtin_fmaf(nz.x, s.iz, s.oz), c1 = __builtin_fmaf(nz.y, s.iz, s.oz);
-      lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
-      lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull));
-      float d0 = __builtin_fmaf(nx.z, s.ix, s.ox), d1 = __builtin_fmaf(nx.w, s.ix, s.ox);
-      float e0 = __builtin_fmaf(ny.z, s.iy, s.oy), e1 = __builtin_fmaf(ny.w, s.iy, s.oy);
-      float f0 = __builtin_fmaf(nz.z, s.iz, s.oz), f1 = __builtin_fmaf(nz.w, s.iz, s.oz);
-      rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
-      rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), s.cull));
-    }
-    bool hl = lmin <= lmax, hr = rmin <= rmax;
-    int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
-    if (hl && hr) {
-      bool swap = rmin < lmin;
-      int nearc = swap ? cr : cl, farc = swap ? cl : cr;
-      float fart = swap ? lmin : rmin;
-      stk_n[s.sp * kBlock + tid] = (uint32_t)farc;
-      (void)fart; (void)stk_t;
-      ++s.sp;
-      s.cur = nearc;
-      return true;
-    } else if (hl) { s.cur = cl; return true; }
-    else if (hr) { s.cur = cr; return true; }
-  } else {
-    uint32_t enc = (uint32_t)~s.cur;
-    uint32_t first = enc >> 3, count = enc & 7u;
-    for (uint32_t k = 0; k < count; ++k) {
-      const float4* q = sc.prims + 3 * (size_t)(first + k);
-      float4 q0 = q[0], q1 = q[1];
-      uint32_t idw = __float_as_uint(q0.w);
-      int id = (int)(idw & 0x7fffffffu);
-      float t; bool hit;
-      s.tests += 1;
-      if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
-      else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t); }
-      if (!hit) continue;
-      if (SHADOW) {
-        float diff = t - s.dist;
-        if (diff < -kEps) { s.occluded = true; return false; }
-        if (diff > kEps) continue;
-      }
-      if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; s.cull = t; }
-    }
-  }
-  // pop the next subtree that can still contain a closer hit
-  // (entries carry no entry distance: a stale subtree costs one node fetch whose boxes then fail the
-  //  cull test, but 4 B per entry instead of 8 doubles the workgroups an LDS-bound CU can hold)
-  if (s.sp > 0) { --s.sp; s.cur = (int)stk_n[s.sp * kBlock + tid]; return true; }
+LR_DEV bool trav_pop(Trav<SHADOW>& s, const uint32_t* stk_n) {
+  if (s.sp > 0) { --s.sp; s.cur = (int)stk_n[s.sp * kBlock + threadIdx.x]; return true; }
   return false;
+}
+
+// One inner node (s.cur >= 0): test both child boxes, descend into the nearer one.  false = ray finished.
+template <bool SHADOW>
+LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
+  const float4* n = sc.nodes + 4 * (size_t)s.cur;
+  float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
+  s.visits += 2;
+  float lmin, lmax, rmin, rmax;
+  {
+#pragma clang fp contract(fast)
+    float a0 = __builtin_fmaf(nx.x, s.ix, s.ox), a1 = __builtin_fmaf(nx.y, s.ix, s.ox);
+    float b0 = __builtin_fmaf(ny.x, s.iy, s.oy), b1 = __builtin_fmaf(ny.y, s.iy, s.oy);
+    float c0 = __builtin_fmaf(nz.x, s.iz, s.oz), c1 = __builtin_fmaf(nz.y, s.iz, s.oz);
+    lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
+    lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull));
+    float d0 = __builtin_fmaf(nx.z, s.ix, s.ox), d1 = __builtin_fmaf(nx.w, s.ix, s.ox);
+    float e0 = __builtin_fmaf(ny.z, s.iy, s.oy), e1 = __builtin_fmaf(ny.w, s.iy, s.oy);
+    float f0 = __builtin_fmaf(nz.z, s.iz, s.oz), f1 = __builtin_fmaf(nz.w, s.iz, s.oz);
+    rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
+    rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), s.cull));
+  }
+  bool hl = lmin <= lmax, hr = rmin <= rmax;
+  int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
+  if (hl && hr) {
+    bool swap = rmin < lmin;
+    stk_n[s.sp * kBlock + threadIdx.x] = (uint32_t)(swap ? cl : cr);
+    ++s.sp;
+    s.cur = swap ? cr : cl;
+    return true;
+  }
+  if (hl) { s.cur = cl; return true; }
+  if (hr) { s.cur = cr; return true; }
+  return trav_pop<SHADOW>(s, stk_n);
+}
+
+// One leaf (s.cur < 0): run the primitive tests of its range.  false = ray finished.
+template <bool SHADOW>
+LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n) {
+  uint32_t enc = (uint32_t)~s.cur;
+  uint32_t first = enc >> 3, count = enc & 7u;
+  for (uint32_t k = 0; k < count; ++k) {
+    const float4* q = sc.prims + 3 * (size_t)(first + k);
+    float4 q0 = q[0], q1 = q[1];
+    uint32_t idw = __float_as_uint(q0.w);
+    int id = (int)(idw & 0x7fffffffu);
+    float t; bool hit;
+    s.tests += 1;
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
+    else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t); }
+    if (!hit) continue;
+    if (SHADOW) {
+      float diff = t - s.dist;
+      if (diff < -kEps) { s.occluded = true; return false; }
+      if (diff > kEps) continue;
+    }
+    if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; s.cull = t; }
+  }
+  return trav_pop<SHADOW>(s, stk_n);
+}
+
+// A burst of traversal for the lanes with `go` set (while-while: the wave first descends inner nodes
+// together, then the lanes that reached a leaf run their primitive tests together).  Clears `go` of lanes
+// whose ray is finished.
+#ifndef LR_DESCEND_BURST
+#define LR_DESCEND_BURST 6
+#endif
+constexpr int kDescendBurst = LR_DESCEND_BURST;
+template <bool SHADOW>
+LR_DEV void trav_burst(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, bool& go) {
+#pragma unroll 1
+  for (int it = 0; it < kDescendBurst; ++it) {
+    bool nm = go && s.cur >= 0;
+    if (__ballot(nm) == 0) break;
+    if (nm) go = trav_node<SHADOW>(sc, s, stk_n);
+  }
+  if (go && s.cur < 0) go = trav_leaf<SHADOW>(sc, s, stk_n);
 }
 
 template <bool SHADOW>
 LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t* stk_n, float* stk_t) {
+  (void)stk_t;
   Trav<SHADOW> s;
   trav_begin<SHADOW>(s, o, d, dist);
-  while (trav_step<SHADOW>(sc, s, stk_n, stk_t)) {}
+  bool go = true;
+  while (__ballot(go) != 0) trav_burst<SHADOW>(sc, s, stk_n, go);
   TraceResult res; res.t = s.t; res.prim = s.prim; res.occluded = s.occluded; res.visits = s.visits; res.tests = s.tests;
   return res;
 }
@@ -683,7 +707,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 //     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use.
 //   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
 constexpr int kMaxGroup = 8;             // segments a workgroup may own at once
-constexpr int kRefillBelow = 44;         // refill the wave when at most this many lanes are still traversing
+#ifndef LR_REFILL_BELOW
+#define LR_REFILL_BELOW 44
+#endif
+constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
 
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
@@ -692,7 +719,6 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
-  float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
   uint32_t n_rays = 0, n_vis = 0, n_tst = 0;
@@ -769,9 +795,9 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
         if (__ballot(has) == 0) { if (exhausted) break; continue; }
         // ---- walk until the wave thins out (or, with nothing left to fetch, until it is done) ----
         const int thresh = exhausted ? 0 : kRefillBelow;
-        do {
-          if (has && !fin) { if (!trav_step<false>(sc, tr, stk_n, stk_t)) fin = true; }
-        } while (__builtin_popcountll(__ballot(has && !fin)) > thresh);
+        bool go = has && !fin;
+        do { trav_burst<false>(sc, tr, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+        fin = has && !go;
       }
     }
     __syncthreads();
@@ -930,7 +956,6 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
-  float* stk_t = (float*)(lds + (size_t)st.stack_depth * kBlock);
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
   uint32_t n_q = 0, n_vis = 0, n_tst = 0;
@@ -986,9 +1011,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
         }
         if (__ballot(has) == 0) break;                              // every drawn entry is a ray: empty wave = list exhausted
         const int thresh = exhausted ? 0 : kRefillBelow;
-        do {
-          if (has && !fin) { if (!trav_step<true>(sc, tr, stk_n, stk_t)) fin = true; }
-        } while (__builtin_popcountll(__ballot(has && !fin)) > thresh);
+        bool go = has && !fin;
+        do { trav_burst<true>(sc, tr, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+        fin = has && !go;
       }
     }
   }
@@ -1064,7 +1089,6 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
   st.hit = (float2*)(lds4 + 7 * kRSeg);
   uint16_t* lists = (uint16_t*)(st.hit + kRSeg);                    // [7][kRSeg]
   uint32_t* stk_n = (uint32_t*)(lists + 7 * kRSeg);
-  float* stk_t = (float*)(stk_n + (size_t)gst.stack_depth * kBlock);
   uint16_t* shq = lists + 6 * kRSeg;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
@@ -1098,7 +1122,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
       if (__float_as_int(ro.w) >= 0) {
         float4 rd = st.ray_d[slot];
         active = true;
-        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, stk_t);
+        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, nullptr);
         st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
         qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
         n_seg += 1;
@@ -1144,7 +1168,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
       float4 ro = st.ray_o[slot];
       float4 sd = st.sh_d[slot];
       V3 o = v3(ro), dir = v3(sd);
-      TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, stk_t);
+      TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, nullptr);
       n_shq += 1;
       shadow_resolve(sc, st, slot, o, dir, r);
     }
@@ -1202,11 +1226,10 @@ __global__ void k_selftest_rng(uint32_t seed, const uint32_t* pixel, const uint3
 __global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, const float4* __restrict__ flat_prims, int stack_depth, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
   extern __shared__ uint32_t lds[];
   uint32_t* stk_n = lds;
-  float* stk_t = (float*)(lds + (size_t)stack_depth * kBlock);
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-  TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, stk_t);
+  TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, nullptr);
   prim_out[i] = r.prim; t_out[i] = r.prim >= 0 ? r.t : 0.0f;
 }
 
