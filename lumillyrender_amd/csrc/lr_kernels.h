@@ -198,7 +198,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
 // together, then the lanes that reached a leaf run their primitive tests together).  Clears `go` of lanes
 // whose ray is finished.
 #ifndef LR_DESCEND_BURST
-#define LR_DESCEND_BURST 6
+#define LR_DESCEND_BURST 4
 #endif
 constexpr int kDescendBurst = LR_DESCEND_BURST;
 template <bool SHADOW>
