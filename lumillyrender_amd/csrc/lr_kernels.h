@@ -1075,9 +1075,12 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
 }
 
 constexpr int kRSeg = 256;               // slots per resident workgroup (one per thread): 34 KB of LDS, 4 workgroups per CU
-constexpr int kResidentStateBytes = 7 * kRSeg * 16 + kRSeg * 8 + 7 * kRSeg * 2;
+constexpr int kResidentStateBytes = 6 * kRSeg * 16 + kRSeg * 8 + 7 * kRSeg * 2;   // ray_o ray_d thr rad sh_d sh_w | hit | 7 lists
 
-__global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+#ifndef LR_RES_WAVES
+#define LR_RES_WAVES 5
+#endif
+__global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
   extern __shared__ float4 lds4[];
   __shared__ PoolLds pl;
   __shared__ uint32_t s_cnt[8];            // [0..5] shade lists, [6] shadow list
@@ -1085,8 +1088,9 @@ __global__ void __launch_bounds__(kBlock, 4) k_resident(DevScene sc, DevState gs
   __shared__ uint32_t s_stat[ST_COUNT];
   DevState st = gst;
   st.ray_o = lds4; st.ray_d = lds4 + kRSeg; st.thr = lds4 + 2 * kRSeg; st.rad = lds4 + 3 * kRSeg;
-  st.acc = lds4 + 4 * kRSeg; st.sh_d = lds4 + 5 * kRSeg; st.sh_w = lds4 + 6 * kRSeg;
-  st.hit = (float2*)(lds4 + 7 * kRSeg);
+  st.sh_d = lds4 + 4 * kRSeg; st.sh_w = lds4 + 5 * kRSeg;
+  st.acc = gst.acc + (size_t)blockIdx.x * kRSeg;                    // chunk sums are touched once per finished sample: they stay in HBM/L2
+  st.hit = (float2*)(lds4 + 6 * kRSeg);
   uint16_t* lists = (uint16_t*)(st.hit + kRSeg);                    // [7][kRSeg]
   uint32_t* stk_n = (uint32_t*)(lists + 7 * kRSeg);
   uint16_t* shq = lists + 6 * kRSeg;

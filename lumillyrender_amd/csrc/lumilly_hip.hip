@@ -290,7 +290,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   bool resident = resident_lds <= 40 * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
-  const int resident_per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (resident_lds + 512))));
+  const int resident_per_cu = std::max(1, std::min(5, (int)((160 * 1024) / (resident_lds + 512))));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : (1u << 20));
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
