@@ -59,7 +59,13 @@ def cpu_baseline(desc, args):
     """Oracle (kind 'port') on all host cores, literal reference traversal (bvh.rs/aabb.rs), on a
     bounded sample: the same 1024x1024 frame at a reduced spp chosen to take ~cpu-seconds."""
     from oracle import binding as oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # a cgroup CPU quota (cpu.max = "quota period") caps what the host threads can really use
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except Exception:
+        pass
     p = desc.render_params(spp=1, seed=0)
     _, st = oracle.render(desc, p, threads=cores, mode=oracle.BVH, pad=0.0, with_stats=True)
     rate1 = st.samples / max(st.seconds, 1e-9)
@@ -69,7 +75,7 @@ def cpu_baseline(desc, args):
     return {
         "value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"{args.width}x{args.height} frame at {spp} spp ({st.samples} samples, {st.seconds:.1f} s), "
-                  "oracle in reference-literal BVH mode, one thread per core",
+                  "oracle in reference-literal BVH mode, one thread per usable core (affinity and cgroup quota)",
     }
 
 
