@@ -657,9 +657,14 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
   }
   uint32_t k = wave_reserve(&pl->taken, need_item);
   bool retired = false;
+  // the pool is a cache of reserved item ids; a lane that finds it empty goes to the global dispenser itself
+  // (one atomic per wave, rare), so a slot only retires when the dispenser is really dry
+  bool short_of = need_item && !(k < pl->a0 + pl->a1);
+  uint32_t direct = wave_reserve(st.next_item, short_of);
   if (need_item) {
     if (k < pl->a0) item = pl->r0 + k;
     else if (k - pl->a0 < pl->a1) item = pl->r1 + (k - pl->a0);
+    else if (direct < st.n_items) item = direct;
     else retired = true;
     if (!retired) {
       uint32_t rank = item % st.n_pix, chunk = item / st.n_pix;
@@ -1074,6 +1079,7 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
   }
 }
 
+constexpr int kPoolBatch = 64, kPoolLow = 24;
 constexpr int kRSeg = 256;               // slots per resident workgroup (one per thread): 34 KB of LDS, 4 workgroups per CU
 constexpr int kResidentStateBytes = 6 * kRSeg * 16 + kRSeg * 8 + 7 * kRSeg * 2;   // ray_o ray_d thr rad sh_d sh_w | hit | 7 lists
 
@@ -1096,7 +1102,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   uint16_t* shq = lists + 6 * kRSeg;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
-  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kRSeg, kRSeg); s_retired = 0; }
+  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kRSeg, kRSeg); s_retired = 0; }   // first fill: one item per slot
   __syncthreads();
   for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
     bool r = finish_and_regenerate(sc, st, rp, &pl, step * kBlock + tid, false, true, v3(0, 0, 0), 1.0f, 0, 0);
@@ -1115,7 +1121,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     const uint32_t retired = s_retired;
     if (retired >= (uint32_t)kRSeg) break;                          // wave-uniform
     if (tid < 8) s_cnt[tid] = 0;
-    if (tid == 8) pool_step(st, &pl, (uint32_t)kRSeg - retired, kRSeg);   // at most one new item per live slot and iteration
+    if (tid == 8) pool_step(st, &pl, kPoolLow, kPoolBatch);          // keep a few iterations of draws in the pool; small batches keep the end-of-render tail short
     __syncthreads();
     LR_TICK(1)
     // ---- phase 1: closest hit for every live slot, compaction by BSDF ----
