@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--streaming", action="store_true", help="force the multi-kernel streaming pipeline")
-    ap.add_argument("--backend", default="cpu:gloo,cuda:nccl", help="torch.distributed backend (testing: gloo)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier (nccl = RCCL; testing: gloo)")
     ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: every rank renders on GPU 0")
     return ap.parse_args()
 
@@ -91,7 +91,9 @@ def main():
     from lumillyrender_amd import abi, device, host, multigpu
 
     dist = None
-    if world > 1:
+    host_group = None
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the env switch exercises the RCCL path on a 1-GPU box
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -100,8 +102,10 @@ def main():
         torch.cuda.set_device(local_rank)
         if "nccl" in args.backend:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            host_group = dist.new_group(backend="gloo")            # the film gather runs on the host
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+            host_group = None
     dev_index = local_rank if world > 1 else 0
 
     W, H = args.width, args.height
@@ -113,7 +117,7 @@ def main():
     flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
     canvas = np.zeros((H, W, 3), dtype=np.float32)
     barrier_buf = None
-    if world > 1:
+    if use_dist:
         barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if "nccl" in args.backend else torch.zeros(1)
 
     def barrier():
@@ -125,7 +129,7 @@ def main():
         params = desc.render_params(spp=spp, seed=i, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=flags, path_slots=args.slots)
         scene.render(params, tiles, n_tiles, out=canvas)      # blocks until the film tiles are on the host
         st = scene.stats()
-        multigpu.gather_film(canvas, dist, dst=0)              # host gather of the disjoint tiles (gloo)
+        multigpu.gather_film(canvas, dist, dst=0, group=host_group)              # host gather of the disjoint tiles (gloo)
         return st
 
     for i in range(args.warmup):
@@ -144,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=host_group)
         elapsed = float(tmax.item())
 
     total_samples = float(W) * H * spp * args.steps

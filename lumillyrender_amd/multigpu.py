@@ -25,11 +25,12 @@ def render_sharded(render_fn, width, height, tile, rank, world, out=None):
     return out
 
 
-def gather_film(film, dist=None, dst=0):
-    """Sum the disjoint per-rank films onto `dst` (host tensors, gloo).  Returns the film on dst."""
+def gather_film(film, dist=None, dst=0, group=None):
+    """Sum the disjoint per-rank films onto `dst` (host tensors; `group` = a gloo group when the default
+    group is NCCL).  Returns the film on dst."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return film
     import torch
     t = torch.from_numpy(film)
-    dist.reduce(t, dst=dst)
+    dist.reduce(t, dst=dst, group=group)
     return film
