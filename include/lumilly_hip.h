@@ -201,6 +201,15 @@ int         lr_render(LrScene* scene, const LrRenderParams* params,
 int         lr_render_device(LrScene* scene, const LrRenderParams* params,
                              const LrTile* tiles, int n_tiles, void** film_dev);
 
+/* Film output stage on the device, applied to the film of the last render (whole film, W*H pixels):
+ *   LR_QUANT_RGB8  3 bytes/pixel, trunc(clamp(x,0,1)^(1/gamma) * 255)          (main.rs:171-173)
+ *   LR_QUANT_RGBE  4 bytes/pixel, Radiance RGBE of the linear value            (img.rs:40-50)
+ * out receives dense rows (row_stride_bytes >= W * bytes/pixel).  lr_host_write_png_rgb8 /
+ * lr_host_write_hdr_rgbe turn the bytes into files. */
+#define LR_QUANT_RGB8 0
+#define LR_QUANT_RGBE 1
+int         lr_film_quantize(LrScene* scene, int mode, float gamma, uint8_t* out, size_t row_stride_bytes);
+
 int         lr_get_stats(LrScene* scene, LrStats* out);
 const char* lr_last_error(void);
 const char* lr_build_info(void);     /* "gfx950 ..." */

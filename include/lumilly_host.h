@@ -74,6 +74,9 @@ void lr_host_free(void* p);
 /* Film output.  rgb = linear f32 radiance, row 0 = top (img.rs:21-27). */
 int  lr_host_save_png(const char* path, const float* rgb, int width, int height, size_t row_stride_floats, float gamma);
 int  lr_host_save_hdr(const char* path, const float* rgb, int width, int height, size_t row_stride_floats);
+/* Same files from already quantized pixels (lr_film_quantize on the device). */
+int  lr_host_write_png_rgb8(const char* path, const uint8_t* rgb8, int width, int height, size_t row_stride_bytes);
+int  lr_host_write_hdr_rgbe(const char* path, const uint8_t* rgbe, int width, int height, size_t row_stride_bytes);
 int  lr_host_to_color(const float* rgb, size_t n, float gamma, uint8_t* out);   /* main.rs:171-173 */
 int  lr_host_load_hdr(const char* path, float** texels_out, int* width_out, int* height_out);
 

@@ -1208,6 +1208,37 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, De
   }
 }
 
+// ---- film output stage on the device (main.rs:171-173 `to_color`, img.rs:40-50 RGBE) -------------------
+// mode 0: 8-bit RGB = trunc(clamp(x, 0, 1)^(1/gamma) * 255); mode 1: Radiance RGBE of the linear film.
+__global__ void __launch_bounds__(kBlock) k_quantize(const float* film, uint8_t* out, uint32_t n_pix, int mode, float inv_gamma) {
+  uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += stride) {
+    float r = film[3 * (size_t)i], g = film[3 * (size_t)i + 1], b = film[3 * (size_t)i + 2];
+    if (mode == 0) {
+      float v[3] = {r, g, b};
+      for (int k = 0; k < 3; ++k) {
+        float c = __builtin_fminf(__builtin_fmaxf(v[k], 0.0f), 1.0f);       // f32::max / min: NaN -> 0
+        float q = det_pow(c, inv_gamma) * 255.0f;
+        out[3 * (size_t)i + k] = !(q > 0.0f) ? 0 : (q >= 255.0f ? 255 : (uint8_t)q);
+      }
+    } else {
+      float mx = __builtin_fmaxf(r, __builtin_fmaxf(g, b));
+      uint8_t c[4] = {0, 0, 0, 0};
+      if (mx > 0.0f && mx < 3.0e38f) {
+        int e; (void)__builtin_frexpf(mx, &e);                            // mx = m * 2^e, m in [0.5, 1)
+        float scale = __builtin_ldexpf(1.0f, 8 - e);                        // exact power of two: v / 2^e * 256
+        float v[3] = {r, g, b};
+        for (int k = 0; k < 3; ++k) {
+          float t = __builtin_truncf(v[k] * scale);
+          c[k] = t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (uint8_t)t);
+        }
+        c[3] = (uint8_t)(e + 128);
+      }
+      out[4 * (size_t)i] = c[0]; out[4 * (size_t)i + 1] = c[1]; out[4 * (size_t)i + 2] = c[2]; out[4 * (size_t)i + 3] = c[3];
+    }
+  }
+}
+
 // ---- diagnostics kernels (lr_selftest_*) ----------------------------------------------------------
 __global__ void k_selftest_math(int fn, const float* a, const float* b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -516,6 +516,27 @@ int lr_render(LrScene* s, const LrRenderParams* params, const LrTile* tiles, int
   })
 }
 
+int lr_film_quantize(LrScene* s, int mode, float gamma, uint8_t* out, size_t row_stride_bytes) {
+  LR_TRY({
+    if (!s || !out || (mode != LR_QUANT_RGB8 && mode != LR_QUANT_RGBE)) fail(LR_EINVAL, "bad argument");
+    if (!s->film.p || s->film_w <= 0) fail(LR_EINVAL, "no film: render first");
+    if (mode == LR_QUANT_RGB8 && !(gamma > 0.0f)) fail(LR_EINVAL, "gamma must be positive");
+    const int W = s->film_w, H = s->film_h, bpp = mode == LR_QUANT_RGB8 ? 3 : 4;
+    if (row_stride_bytes < (size_t)W * bpp) fail(LR_EINVAL, "row stride smaller than one row");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<uint8_t> q; q.ensure((size_t)W * H * bpp);
+    uint32_t n_pix = (uint32_t)((size_t)W * H);
+    int grid = (int)std::min<size_t>(((size_t)n_pix + kBlock - 1) / kBlock, (size_t)s->n_cus * 8);
+    hipLaunchKernelGGL(k_quantize, dim3(grid), dim3(kBlock), 0, s->stream, s->film.p, q.p, n_pix, mode, 1.0f / gamma);
+    HIP_OK(hipGetLastError());
+    std::vector<uint8_t> host((size_t)W * H * bpp);
+    HIP_OK(hipMemcpyAsync(host.data(), q.p, host.size(), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (int y = 0; y < H; ++y) std::memcpy(out + (size_t)y * row_stride_bytes, host.data() + (size_t)y * W * bpp, (size_t)W * bpp);
+    q.release();
+  })
+}
+
 int lr_get_stats(LrScene* s, LrStats* out) {
   if (!s || !out) { g_err = "null argument"; return LR_EINVAL; }
   *out = s->stats;

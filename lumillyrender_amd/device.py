@@ -37,6 +37,7 @@ def lib():
     l.lr_render.argtypes = [vp, C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int, fp, C.c_size_t]
     l.lr_render_device.argtypes = [vp, C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int, C.POINTER(vp)]
     l.lr_get_stats.argtypes = [vp, C.POINTER(abi.LrStats)]
+    l.lr_film_quantize.argtypes = [vp, C.c_int, C.c_float, C.POINTER(C.c_uint8), C.c_size_t]
     l.lr_selftest_math.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_int]
     up = C.POINTER(C.c_uint32)
     l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
@@ -99,6 +100,14 @@ class Scene:
         p = C.c_void_p()
         _check(lib().lr_render_device(self._h, C.byref(params), tiles, n_tiles, C.byref(p)))
         return p.value
+
+    def quantize(self, mode="rgb8", gamma=2.2):
+        """Film output stage on the device for the last render: (H, W, 3) uint8 with the reference's
+        gamma/truncation (main.rs:171-173) or (H, W, 4) Radiance RGBE bytes."""
+        bpp = 3 if mode == "rgb8" else 4
+        out = np.empty((self.height, self.width, bpp), dtype=np.uint8)
+        _check(lib().lr_film_quantize(self._h, 0 if mode == "rgb8" else 1, gamma, out.ctypes.data_as(C.POINTER(C.c_uint8)), self.width * bpp))
+        return out
 
     def stats(self):
         s = abi.LrStats()

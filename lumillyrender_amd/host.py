@@ -49,6 +49,9 @@ def _load():
     fp = C.POINTER(C.c_float)
     lib.lr_host_save_png.argtypes = [C.c_char_p, fp, C.c_int, C.c_int, C.c_size_t, C.c_float]
     lib.lr_host_save_hdr.argtypes = [C.c_char_p, fp, C.c_int, C.c_int, C.c_size_t]
+    bp = C.POINTER(C.c_uint8)
+    lib.lr_host_write_png_rgb8.argtypes = [C.c_char_p, bp, C.c_int, C.c_int, C.c_size_t]
+    lib.lr_host_write_hdr_rgbe.argtypes = [C.c_char_p, bp, C.c_int, C.c_int, C.c_size_t]
     lib.lr_host_to_color.argtypes = [fp, C.c_size_t, C.c_float, C.POINTER(C.c_uint8)]
     lib.lr_host_load_hdr.argtypes = [C.c_char_p, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.lr_host_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.LrTile), C.c_int]
@@ -179,6 +182,18 @@ def save_hdr(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     h, w, _ = rgb.shape
     _check(lib().lr_host_save_hdr(os.fspath(path).encode(), _fptr(rgb), w, h, w * 3))
+
+
+def write_png_rgb8(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    _check(lib().lr_host_write_png_rgb8(os.fspath(path).encode(), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, w * 3))
+
+
+def write_hdr_rgbe(path, rgbe):
+    rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
+    h, w, _ = rgbe.shape
+    _check(lib().lr_host_write_hdr_rgbe(os.fspath(path).encode(), rgbe.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, w * 4))
 
 
 def load_hdr(path):

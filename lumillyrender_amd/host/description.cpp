@@ -311,6 +311,12 @@ int lr_host_save_png(const char* path, const float* rgb, int w, int h, size_t st
 int lr_host_save_hdr(const char* path, const float* rgb, int w, int h, size_t stride) {
   LR_HOST_TRY({ if (!path || !rgb) fail(LR_EINVAL, "null argument"); save_hdr(path, rgb, w, h, stride); })
 }
+int lr_host_write_png_rgb8(const char* path, const uint8_t* rgb8, int w, int h, size_t stride) {
+  LR_HOST_TRY({ if (!path || !rgb8) fail(LR_EINVAL, "null argument"); write_png_rgb8(path, rgb8, w, h, stride); })
+}
+int lr_host_write_hdr_rgbe(const char* path, const uint8_t* rgbe, int w, int h, size_t stride) {
+  LR_HOST_TRY({ if (!path || !rgbe) fail(LR_EINVAL, "null argument"); write_hdr_rgbe(path, rgbe, w, h, stride); })
+}
 int lr_host_to_color(const float* rgb, size_t n, float gamma, uint8_t* out) {
   if (!rgb || !out) { set_last_error("null argument"); return LR_EINVAL; }
   for (size_t i = 0; i < n; ++i) out[i] = to_color(rgb[i], gamma);

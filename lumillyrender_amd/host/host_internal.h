@@ -72,6 +72,8 @@ void load_hdr(const std::string& path, std::vector<float>& texels, int& w, int& 
 void save_hdr(const std::string& path, const float* rgb, int w, int h, size_t stride);
 void save_png(const std::string& path, const float* rgb, int w, int h, size_t stride, float gamma);
 uint8_t to_color(float x, float gamma);
+void write_png_rgb8(const std::string& path, const uint8_t* rgb8, int w, int h, size_t stride);
+void write_hdr_rgbe(const std::string& path, const uint8_t* rgbe, int w, int h, size_t stride);
 
 std::string resolve_path(const std::string& path, const std::string& asset_root);
 

@@ -38,7 +38,7 @@ Rgbe to_rgbe8(float r, float g, float b) {
   Rgbe o; std::memset(&o, 0, sizeof(o));
   float mx = std::fmax(r, std::fmax(g, b));
   if (!(mx > 0.0f)) return o;
-  int exp = (int)std::floor(std::log2(mx)) + 1;
+  int exp; (void)std::frexp(mx, &exp);                       // mx = m * 2^exp, m in [0.5, 1)  (= floor(log2 mx) + 1)
   float mul = std::ldexp(1.0f, exp);
   float v[3] = {r, g, b};
   for (int k = 0; k < 3; ++k) {
@@ -72,11 +72,19 @@ void rle_channel(std::vector<uint8_t>& out, const uint8_t* d, int n) {
 
 void save_png(const std::string& path, const float* rgb, int w, int h, size_t stride, float gamma) {
   if (w <= 0 || h <= 0) fail(LR_EINVAL, "png: empty image");
+  std::vector<uint8_t> q((size_t)w * h * 3);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w * 3; ++x) q[(size_t)y * w * 3 + x] = to_color(rgb[(size_t)y * stride + x], gamma);
+  write_png_rgb8(path, q.data(), w, h, (size_t)w * 3);
+}
+
+void write_png_rgb8(const std::string& path, const uint8_t* rgb8, int w, int h, size_t stride) {
+  if (w <= 0 || h <= 0) fail(LR_EINVAL, "png: empty image");
   std::vector<uint8_t> raw((size_t)h * ((size_t)w * 3 + 1));
   for (int y = 0; y < h; ++y) {
     uint8_t* row = raw.data() + (size_t)y * ((size_t)w * 3 + 1);
     row[0] = 0;                                                  // filter: none
-    for (int x = 0; x < w * 3; ++x) row[1 + x] = to_color(rgb[(size_t)y * stride + x], gamma);
+    std::memcpy(row + 1, rgb8 + (size_t)y * stride, (size_t)w * 3);
   }
   uLongf clen = compressBound((uLong)raw.size());
   std::vector<uint8_t> comp(clen);
@@ -96,6 +104,19 @@ void save_png(const std::string& path, const float* rgb, int w, int h, size_t st
 
 void save_hdr(const std::string& path, const float* rgb, int w, int h, size_t stride) {
   if (w <= 0 || h <= 0) fail(LR_EINVAL, "hdr: empty image");
+  std::vector<uint8_t> q((size_t)w * h * 4);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const float* p = rgb + (size_t)y * stride + (size_t)x * 3;
+      Rgbe e = to_rgbe8(p[0], p[1], p[2]);
+      uint8_t* o = q.data() + ((size_t)y * w + x) * 4;
+      o[0] = e.c[0]; o[1] = e.c[1]; o[2] = e.c[2]; o[3] = e.e;
+    }
+  write_hdr_rgbe(path, q.data(), w, h, (size_t)w * 4);
+}
+
+void write_hdr_rgbe(const std::string& path, const uint8_t* rgbe, int w, int h, size_t stride) {
+  if (w <= 0 || h <= 0) fail(LR_EINVAL, "hdr: empty image");
   std::ofstream f(path, std::ios::binary);
   if (!f) fail(LR_EIO, "hdr: cannot create `" + path + "`");
   char hdr[128];
@@ -105,8 +126,8 @@ void save_hdr(const std::string& path, const float* rgb, int w, int h, size_t st
   std::vector<uint8_t> chan((size_t)w), out;
   for (int y = 0; y < h; ++y) {
     for (int x = 0; x < w; ++x) {
-      const float* p = rgb + (size_t)y * stride + (size_t)x * 3;
-      line[x] = to_rgbe8(p[0], p[1], p[2]);
+      const uint8_t* p = rgbe + (size_t)y * stride + (size_t)x * 4;
+      line[x].c[0] = p[0]; line[x].c[1] = p[1]; line[x].c[2] = p[2]; line[x].e = p[3];
     }
     out.clear();
     if (w < 8 || w > 32767) {

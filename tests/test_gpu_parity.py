@@ -382,3 +382,26 @@ def test_bvh_path_on_a_small_scene(dev, oracle):
         assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
         assert linf(img, ref) < TOL
     scene.close()
+
+
+def test_device_film_output_stage(dev, tmp_path):
+    """quantisation on the device (main.rs:171-173 gamma + truncation; img.rs:40-50 RGBE)
+    against the host writers, which are pinned on CPU by tests/test_host_loader.py."""
+    from lumillyrender_amd import host
+    desc = load("brdf-row.toml", 96, 54)               # hdr scene with values above 1
+    scene = dev.Scene(desc)
+    film = scene.render(desc.render_params(spp=16, seed=1))
+    # RGBE: integer-exact on both sides -> identical bytes, identical files after decode
+    rgbe = scene.quantize("rgbe")
+    host.write_hdr_rgbe(tmp_path / "dev.hdr", rgbe)
+    host.save_hdr(tmp_path / "host.hdr", film)
+    assert np.array_equal(host.load_hdr(tmp_path / "dev.hdr"), host.load_hdr(tmp_path / "host.hdr"))
+    # RGB8: powf on the host vs the device's own pow series: equal except for rare bucket-edge pixels (off by one)
+    q = scene.quantize("rgb8", gamma=2.2)
+    ref = host.to_color(film, 2.2)
+    diff = np.abs(q.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3
+    host.write_png_rgb8(tmp_path / "dev.png", q)
+    from PIL import Image
+    assert np.array_equal(np.array(Image.open(tmp_path / "dev.png").convert("RGB")), q)
+    scene.close()
