@@ -405,3 +405,63 @@ def test_device_film_output_stage(dev, tmp_path):
     from PIL import Image
     assert np.array_equal(np.array(Image.open(tmp_path / "dev.png").convert("RGB")), q)
     scene.close()
+
+
+def test_device_api_rejects_bad_input(dev):
+    """Error behaviour at the boundary: the reference panics (main.rs:48,124,166; description.rs:34-178),
+    the C ABI returns LR_E* codes with a message and stays usable."""
+    import ctypes as C
+    from lumillyrender_amd import abi, host
+    desc = load("cbox-spheres.toml", 16, 16)
+    d = desc.desc
+    h = C.c_void_p()
+    lib = dev.lib()
+    # wrong ABI version / no such device
+    bad = abi.LrSceneDesc.from_buffer_copy(d)
+    bad.abi_version = 99
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL and b"abi_version" in lib.lr_last_error()
+    assert lib.lr_scene_create(4096, desc.desc_ptr, C.byref(h)) == abi.LR_EINVAL
+    # a BVH that does not cover every primitive
+    bad = abi.LrSceneDesc.from_buffer_copy(d)
+    bad.n_prims = d.n_prims - 1
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
+    # material index out of range
+    prims = (abi.LrPrimitive * d.n_prims)()
+    C.memmove(prims, d.prims, C.sizeof(prims))
+    prims[3].material = 1000
+    bad = abi.LrSceneDesc.from_buffer_copy(d)
+    bad.prims = C.cast(prims, C.POINTER(abi.LrPrimitive))
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
+    # render-time errors leave the scene usable
+    scene = dev.Scene(desc)
+    for kw in ({"spp": 0}, {"spp": -3}):
+        with pytest.raises(host.LumillyError):
+            scene.render(desc.render_params(**kw))
+    p = desc.render_params(spp=2)
+    p.integrator = 7
+    with pytest.raises(host.LumillyError):
+        scene.render(p)
+    with pytest.raises(host.LumillyError):
+        scene.quantize("rgb8", gamma=0.0)
+    img = scene.render(desc.render_params(spp=2, seed=1))
+    assert np.isfinite(img).all() and img.max() > 0
+    scene.close()
+    scene.close()                                        # double close is harmless
+
+
+def test_two_scenes_render_concurrently(dev, oracle):
+    """Different LrScene handles may be driven from different host threads (one stream each)."""
+    import threading
+    descs = [load("cbox-spheres.toml", 48, 48), load("brdf-row.toml", 64, 36)]
+    scenes = [dev.Scene(d) for d in descs]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(3):
+            out[i] = scenes[i].render(descs[i].render_params(spp=16, seed=4))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(2):
+        assert linf(out[i], oracle.render(descs[i], descs[i].render_params(spp=16, seed=4))) < TOL
+        scenes[i].close()
