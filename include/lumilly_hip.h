@@ -128,7 +128,8 @@ typedef struct LrSceneDesc {
   int32_t            n_prims;
   const LrPrimitive* prims;
   LrSky              sky;
-  int32_t            n_bvh_nodes;    /* >= 1 (node 0 is the root)                            */
+  int32_t            n_bvh_nodes;    /* >= 1 (node 0 is the root); 0 with bvh_nodes == NULL: the library
+                                        builds an LBVH on the device (replaces bvh.rs:56-127 there)   */
   const LrBvhNode*   bvh_nodes;
   const int32_t*     bvh_prim_order; /* n_prims entries: leaf ranges index into this          */
   int32_t            bvh_max_depth;  /* max number of inner nodes on a root-to-leaf path      */
@@ -180,6 +181,7 @@ typedef struct LrStats {
   uint64_t kernel_timed[LR_K_COUNT]; /* number of launches that were event-timed             */
   double   render_ms;                /* wall time of the last lr_render, device work only    */
   double   upload_ms;                /* lr_scene_create                                      */
+  double   bvh_build_ms;             /* device LBVH build inside lr_scene_create (0 = host tree) */
 } LrStats;
 
 typedef struct LrScene LrScene;      /* opaque */

@@ -96,6 +96,7 @@ class LrStats(C.Structure):
         ("kernel_timed", u64 * LR_K_COUNT),
         ("render_ms", C.c_double),
         ("upload_ms", C.c_double),
+        ("bvh_build_ms", C.c_double),
     ]
 
 

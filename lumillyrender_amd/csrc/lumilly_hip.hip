@@ -15,6 +15,7 @@
 
 #include "../../include/lumilly_hip.h"
 #include "lr_kernels.h"
+#include "lr_lbvh.h"
 
 using namespace lr;
 
@@ -70,6 +71,7 @@ struct LrScene {
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
   int stack_depth = 2;
+  double bvh_build_ms = 0.0;           // device LBVH build time (0 when the host supplied the tree)
   int film_w = 0, film_h = 0;
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
@@ -92,7 +94,8 @@ namespace {
 void pack_scene(LrScene& s, const LrSceneDesc& d) {
   if (d.abi_version != LR_ABI_VERSION) fail(LR_EINVAL, "LrSceneDesc.abi_version mismatch");
   if (d.n_prims < 0 || d.n_materials < 0 || (d.n_prims > 0 && (!d.prims || !d.materials))) fail(LR_EINVAL, "bad primitive / material arrays");
-  if (d.n_bvh_nodes < 1 || !d.bvh_nodes || (d.n_prims > 0 && !d.bvh_prim_order)) fail(LR_EINVAL, "missing BVH (build it with lr_host_build_bvh)");
+  const bool device_bvh = d.n_bvh_nodes == 0 && !d.bvh_nodes;            // no tree supplied: build an LBVH on the device
+  if (!device_bvh && (d.n_bvh_nodes < 1 || !d.bvh_nodes || (d.n_prims > 0 && !d.bvh_prim_order))) fail(LR_EINVAL, "malformed BVH (build it with lr_host_build_bvh, or pass n_bvh_nodes = 0 for a device build)");
   if (d.camera.resolution[0] <= 0 || d.camera.resolution[1] <= 0) fail(LR_EINVAL, "bad film resolution");
   if ((uint64_t)d.camera.resolution[0] * (uint64_t)d.camera.resolution[1] > 0xffffffffull) fail(LR_EINVAL, "film too large");
   if (d.camera.type < 0 || d.camera.type > LR_CAMERA_OMNIDIRECTIONAL) fail(LR_EINVAL, "unknown camera type");
@@ -163,39 +166,71 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // BVH nodes + primitives in leaf order
-  std::vector<float4> nodes((size_t)d.n_bvh_nodes * 4), prims((size_t)std::max(np, 1) * 3);
-  std::vector<char> seen((size_t)np, 0);
-  for (int i = 0; i < d.n_bvh_nodes; ++i) {
-    const LrBvhNode& n = d.bvh_nodes[i];
-    nodes[4 * i] = make_float4(n.x[0], n.x[1], n.x[2], n.x[3]);
-    nodes[4 * i + 1] = make_float4(n.y[0], n.y[1], n.y[2], n.y[3]);
-    nodes[4 * i + 2] = make_float4(n.z[0], n.z[1], n.z[2], n.z[3]);
-    nodes[4 * i + 3] = make_float4(__builtin_bit_cast(float, n.child[0]), __builtin_bit_cast(float, n.child[1]), 0.0f, 0.0f);
-    for (int c = 0; c < 2; ++c) {
-      int ch = n.child[c];
-      if (ch >= 0) { if (ch >= d.n_bvh_nodes || ch <= i) fail(LR_EINVAL, "BVH child index out of order"); continue; }
-      uint32_t enc = (uint32_t)~ch, first = enc >> 3, count = enc & 7u;
-      if ((uint64_t)first + count > (uint64_t)np) fail(LR_EINVAL, "BVH leaf range out of bounds");
-      for (uint32_t k = first; k < first + count; ++k) {
-        int id = d.bvh_prim_order[k];
-        if (id < 0 || id >= np || seen[id]) fail(LR_EINVAL, "BVH primitive order is not a permutation");
-        seen[id] = 1;
-        const LrPrimitive& p = d.prims[id];
-        if (p.type == LR_PRIM_TRIANGLE) {                        // e1, e2 of triangle.rs:71-72
-          prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
-          prims[3 * k + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
-          prims[3 * k + 2] = make_float4(p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2], 0.0f);
-        } else {
-          prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id | 0x80000000u));
-          prims[3 * k + 1] = make_float4(p.v[3], p.v[3] * p.v[3], 0.0f, 0.0f);
-          prims[3 * k + 2] = make_float4(0, 0, 0, 0);
+  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3);
+  s.bvh_build_ms = 0.0;
+  bool built_on_device = false;
+  if (device_bvh && np >= 2) {
+    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3);
+    int height = 0; std::string err;
+    int rc = lbvh_build(d.prims, np, d.camera.aperture_position, s.stream, s.nodes.p, s.prims.p, &height, &s.bvh_build_ms, err);
+    if (rc != LR_OK) fail(rc, "device BVH build: " + err);
+    if (height < 1 || height > 95) fail(LR_EUNSUPPORTED, "device BVH too deep for the traversal stack (" + std::to_string(height) + ")");
+    s.stack_depth = height + 1;
+    built_on_device = true;
+  } else if (device_bvh) {
+    // 0 or 1 primitive: a root with (at most) one leaf
+    nodes.assign(4, make_float4(0, 0, 0, 0));
+    int leaf = np == 1 ? ~(int)((0u << 3) | 1u) : ~0;
+    if (np == 1) {
+      const LrPrimitive& p = d.prims[0];
+      float big = 3.0e38f;
+      nodes[0] = make_float4(-big, big, 0, 0); nodes[1] = make_float4(-big, big, 0, 0); nodes[2] = make_float4(-big, big, 0, 0);
+      if (p.type == LR_PRIM_TRIANGLE) {
+        prims[0] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, 0u));
+        prims[1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
+        prims[2] = make_float4(p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2], 0.0f);
+      } else {
+        prims[0] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, 0x80000000u));
+        prims[1] = make_float4(p.v[3], p.v[3] * p.v[3], 0.0f, 0.0f);
+      }
+    }
+    nodes[3] = make_float4(__builtin_bit_cast(float, leaf), __builtin_bit_cast(float, ~0), 0.0f, 0.0f);
+    s.stack_depth = 2;
+  } else {
+    nodes.assign((size_t)d.n_bvh_nodes * 4, make_float4(0, 0, 0, 0));
+    std::vector<char> seen((size_t)np, 0);
+    for (int i = 0; i < d.n_bvh_nodes; ++i) {
+      const LrBvhNode& n = d.bvh_nodes[i];
+      nodes[4 * i] = make_float4(n.x[0], n.x[1], n.x[2], n.x[3]);
+      nodes[4 * i + 1] = make_float4(n.y[0], n.y[1], n.y[2], n.y[3]);
+      nodes[4 * i + 2] = make_float4(n.z[0], n.z[1], n.z[2], n.z[3]);
+      nodes[4 * i + 3] = make_float4(__builtin_bit_cast(float, n.child[0]), __builtin_bit_cast(float, n.child[1]), 0.0f, 0.0f);
+      for (int c = 0; c < 2; ++c) {
+        int ch = n.child[c];
+        if (ch >= 0) { if (ch >= d.n_bvh_nodes || ch <= i) fail(LR_EINVAL, "BVH child index out of order"); continue; }
+        uint32_t enc = (uint32_t)~ch, first = enc >> 3, count = enc & 7u;
+        if ((uint64_t)first + count > (uint64_t)np) fail(LR_EINVAL, "BVH leaf range out of bounds");
+        for (uint32_t k = first; k < first + count; ++k) {
+          int id = d.bvh_prim_order[k];
+          if (id < 0 || id >= np || seen[id]) fail(LR_EINVAL, "BVH primitive order is not a permutation");
+          seen[id] = 1;
+          const LrPrimitive& p = d.prims[id];
+          if (p.type == LR_PRIM_TRIANGLE) {                        // e1, e2 of triangle.rs:71-72
+            prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
+            prims[3 * k + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
+            prims[3 * k + 2] = make_float4(p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2], 0.0f);
+          } else {
+            prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id | 0x80000000u));
+            prims[3 * k + 1] = make_float4(p.v[3], p.v[3] * p.v[3], 0.0f, 0.0f);
+            prims[3 * k + 2] = make_float4(0, 0, 0, 0);
+          }
         }
       }
     }
+    for (int i = 0; i < np; ++i) if (!seen[i]) fail(LR_EINVAL, "BVH does not reference every primitive");
+    if (d.bvh_max_depth < 1 || d.bvh_max_depth > 96) fail(LR_EINVAL, "bvh_max_depth out of range (1..96)");
+    s.stack_depth = d.bvh_max_depth + 1;
   }
-  for (int i = 0; i < np; ++i) if (!seen[i]) fail(LR_EINVAL, "BVH does not reference every primitive");
-  if (d.bvh_max_depth < 1 || d.bvh_max_depth > 96) fail(LR_EINVAL, "bvh_max_depth out of range (1..96)");
-  s.stack_depth = d.bvh_max_depth + 1;
 
   std::vector<float4> texels;
   if (d.sky.type == LR_SKY_IBL) {
@@ -205,7 +240,8 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     for (size_t i = 0; i < n; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
   } else if (d.sky.type != LR_SKY_UNIFORM) fail(LR_EINVAL, "unknown sky type");
 
-  s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); s.shade.upload(shade, s.stream);
+  if (!built_on_device) { s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); }
+  s.shade.upload(shade, s.stream);
   s.mats.upload(mats, s.stream); s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
   s.prim_qid.upload(qid, s.stream);
   HIP_OK(hipStreamSynchronize(s.stream));
@@ -330,8 +366,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   dp.depth_limit = rp_in.depth_limit; dp.no_direct_emitter = rp_in.no_direct_emitter ? 1 : 0;
 
   LrStats& S = s.stats;
-  double keep_upload = S.upload_ms;
-  std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload;
+  double keep_upload = S.upload_ms, keep_bvh = S.bvh_build_ms;
+  std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload; S.bvh_build_ms = keep_bvh;
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
@@ -467,6 +503,7 @@ int lr_scene_create(int device, const LrSceneDesc* desc, LrScene** out) {
     std::memset(&s->stats, 0, sizeof(s->stats));
     pack_scene(*s, *desc);
     s->stats.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->stats.bvh_build_ms = s->bvh_build_ms;
     *out = s;
     return LR_OK;
   } catch (const ApiError& e) { g_err = e.msg; if (s) lr_scene_destroy(s); return e.code; }

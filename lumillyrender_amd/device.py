@@ -63,12 +63,21 @@ def _fptr(a):
 class Scene:
     """Device-resident scene (BVH, primitives, materials, emitters, sky) on one GPU."""
 
-    def __init__(self, description, device=0):
+    def __init__(self, description, device=0, device_bvh=False):
+        """device_bvh=True drops the host SAH tree from the description so that lr_scene_create builds an
+        LBVH on the GPU (same images: the tree only prunes)."""
         self._h = C.c_void_p()
         self.description = description            # keeps the host arrays alive during create
         if device_count() <= 0:
             raise RuntimeError("lumilly_hip: no HIP device visible (the render path has no CPU fallback)")
-        _check(lib().lr_scene_create(device, description.desc_ptr, C.byref(self._h)))
+        ptr = description.desc_ptr
+        if device_bvh:
+            d = abi.LrSceneDesc.from_buffer_copy(description.desc)
+            d.n_bvh_nodes, d.bvh_max_depth = 0, 0
+            d.bvh_nodes = C.POINTER(abi.LrBvhNode)()
+            d.bvh_prim_order = C.POINTER(C.c_int32)()
+            ptr = C.pointer(d)
+        _check(lib().lr_scene_create(device, ptr, C.byref(self._h)))
         d = description.desc
         self.width, self.height = int(d.camera.resolution[0]), int(d.camera.resolution[1])
         self.device = device
@@ -149,6 +158,7 @@ def stats_dict(s):
     d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests", "sky_fetches", "iterations")}
     d["render_ms"] = float(s.render_ms)
     d["upload_ms"] = float(s.upload_ms)
+    d["bvh_build_ms"] = float(s.bvh_build_ms)
     d["kernels"] = {
         abi.LR_KERNEL_NAMES[k]: {"launches": int(s.kernel_launches[k]), "timed": int(s.kernel_timed[k]), "ms": float(s.kernel_ms[k])}
         for k in range(abi.LR_K_COUNT)

@@ -465,3 +465,32 @@ def test_two_scenes_render_concurrently(dev, oracle):
     for i in range(2):
         assert linf(out[i], oracle.render(descs[i], descs[i].render_params(spp=16, seed=4))) < TOL
         scenes[i].close()
+
+
+@pytest.mark.parametrize("name", ["cbox-spheres.toml", "two-spheres.toml", "mesh-box.toml"])
+def test_device_built_bvh_gives_the_same_film(dev, oracle, name):
+    """an LBVH built on the device (Morton sort + Karras tree + bottom-up fit) instead of the
+    host SAH tree (bvh.rs:56-127).  The tree only prunes, so films and hit records are bit-identical."""
+    from lumillyrender_amd import abi
+    if name == "mesh-box.toml" and not _generated_assets():
+        pytest.skip("generated assets missing")
+    desc = load(name, 64, 48)
+    a, b = dev.Scene(desc), dev.Scene(desc, device_bvh=True)
+    assert a.stats().bvh_build_ms == 0.0 and b.stats().bvh_build_ms > 0.0
+    flags = abi.LR_FLAG_STREAMING if name != "mesh-box.toml" else 0        # force the tree walk on the small scenes
+    for sc_flags in (flags, flags | abi.LR_FLAG_RESIDENT if name != "mesh-box.toml" else flags):
+        p = desc.render_params(spp=8, seed=31, flags=sc_flags)
+        fa, fb = a.render(p), b.render(p)
+        assert np.array_equal(fa, fb)
+        assert (a.stats().segments, a.stats().shadow_rays) == (b.stats().segments, b.stats().shadow_rays)
+    if name == "mesh-box.toml":
+        rng = np.random.default_rng(3)
+        o = (rng.random((20000, 3)) * [556, 548, 559]).astype(np.float32)
+        d = (np.array([255, 95, 278]) + rng.standard_normal((20000, 3)) * 90 - o).astype(np.float32)
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        o, d = _random_rays(desc, 20000, 5)
+    pa, ta = a.intersect(o, d)
+    pb, tb = b.intersect(o, d)
+    assert np.array_equal(pa, pb) and np.array_equal(ta, tb)
+    a.close(); b.close()
