@@ -6,8 +6,9 @@
 //   prims   3 x float4 per primitive (48 B) IN LEAF ORDER, so a leaf reads consecutive rows:
 //             triangle  {p0.xyz, id} {e1.xyz, -} {e2.xyz, -}     e1 = p1-p0, e2 = p2-p0 (triangle.rs:71-72)
 //             sphere    {c.xyz, id | 1<<31} {r, r*r, -, -} {-}
-//   shade   1 x float4 per primitive id: {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
-//   mats    3 x float4 per material: {color.rgb, type} {emission.rgb, weight} {param0..2, -}
+//   shade   4 x float4 per primitive id (64 B, one cache line, the four loads of a vertex go out together):
+//             {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
+//             {color.rgb, type} {emission.rgb, weight} {param0..2, -}    = the primitive's material, denormalised
 //   emit    3 x float4 per emitter (objects.rs:19-24, instance order):
 //             {p0|c .xyz, type} {p1.xyz | r, pdf} {p2.xyz, cumulative area}
 //   texels  float4 per IBL texel (rgb, -)
@@ -48,7 +49,6 @@ struct DevScene {
   const float4* nodes;
   const float4* prims;
   const float4* shade;
-  const float4* mats;
   const float4* emit;
   const float4* texels;
   const uint8_t* prim_qid;             // per primitive id: shade queue (= material type)
@@ -82,6 +82,7 @@ struct DevState {
   float*  film;                        // W*H*3
   const int4* tiles;                   // x0, y0, w, h
   const uint32_t* tile_prefix;         // n_tiles + 1
+  uint32_t* rank_pixel;                // n_pix: film pixel of every pixel rank (k_rank_table), one load instead of a search per work item
   int n_tiles;
   uint32_t n_slots, n_seg, n_pix, n_chunks, chunk_spp, n_items;
   int stack_depth;                     // LDS traversal stack entries per lane

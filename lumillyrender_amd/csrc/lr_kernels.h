@@ -223,54 +223,93 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
   return res;
 }
 
+#ifndef LR_FLAT_BALLOTS
+#define LR_FLAT_BALLOTS 2
+#endif
+typedef float RowVec __attribute__((ext_vector_type(4)));
+typedef RowVec __attribute__((address_space(4))) ConstRow;
+LR_DEV float4 row4(RowVec v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+// Compiler fence for prefetched scalar rows: an empty asm that "uses" the 12 SGPRs, so the s_waitcnt for
+// the prefetch (and the register shuffles the packed-math operands need) sits here, after the previous
+// primitive's test, and not directly behind the s_load.
+LR_DEV void sgpr_pin(float4& a, float4& b, float4& c) {
+  asm volatile("" : "+s"(a.x), "+s"(a.y), "+s"(a.z), "+s"(a.w), "+s"(b.x), "+s"(b.y), "+s"(b.z), "+s"(b.w),
+                    "+s"(c.x), "+s"(c.y), "+s"(c.z), "+s"(c.w));
+}
+
+// One primitive of the flat loop: triangle.rs:69-100 / sphere.rs:42-55 and the closest-hit fold.  Returns
+// true when the loop may stop (SHADOW: every lane of the wave already knows it is occluded).
+template <bool SHADOW>
+LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, TraceResult& res) {
+  uint32_t idw = __float_as_uint(q0.w);
+  int id = (int)(idw & 0x7fffffffu);
+  float t = 0.0f; bool hit = false;
+  // booleans are combined with & and | (no short circuit): the lane masks stay in SGPRs and the only
+  // branches left are the wave-uniform ones
+  if (idw >> 31) {
+    hit = sphere_test(v3(q0), q1.y, o, d, &t);
+  } else {
+    // same operations as tri_test(); the __ballot tests only skip work that no lane of the wave
+    // needs (all lanes already rejected), they never change a result
+    V3 p0 = v3(q0), e1 = v3(q1), e2 = v3(q2);
+    V3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    float invdet = 1.0f / det;
+    V3 tv = o - p0;
+    float u = dot(tv, pv) * invdet;
+    bool ok = bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f));
+#if LR_FLAT_BALLOTS >= 2
+    if (__ballot(ok) != 0)
+#endif
+    {
+      V3 qv = cross(tv, e1);
+      float v = dot(d, qv) * invdet;
+      ok = ok & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f));
+#if LR_FLAT_BALLOTS >= 1
+      if (__ballot(ok) != 0)
+#endif
+      {
+        t = dot(e2, qv) * invdet;
+        hit = ok & bool(!(t < kEps));
+      }
+    }
+  }
+  if (SHADOW) {
+    float diff = t - dist;
+    res.occluded = res.occluded | (hit & bool(diff < -kEps));
+    hit = hit & bool(!(diff > kEps));
+  }
+  bool better = hit & (bool(t < res.t) | (bool(t == res.t) & bool(id < res.prim)));
+  res.t = better ? t : res.t;
+  res.prim = better ? id : res.prim;
+  return SHADOW && __ballot(!res.occluded) == 0;
+}
+
 // Small scenes (n_flat = number of primitives when <= kFlatMax, else 0): the SAH says a tree over a
 // dozen primitives saves almost nothing, so the "tree" is one leaf and every lane tests every
 // primitive.  The loop index is wave-uniform, so the primitive rows arrive through the scalar cache
 // into SGPRs (s_load_dwordx4) and the loop is pure, fully converged VALU: no vector memory traffic,
 // no stack, no divergence.  Same tests, same tie rule => same result as traverse().
+// The loop is unrolled by two over two register sets (A, B): the rows of primitive k+1 are requested
+// before primitive k is tested and nothing touches them until that test is done, so the scalar-cache
+// latency hides behind ~50 VALU instructions instead of stalling every iteration.
 template <bool SHADOW>
 LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, int n, V3 o, V3 d, float dist) {
-  TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = 0;
-  // rows of primitive k+1 are requested (s_load) before primitive k is tested
-  float4 n0 = prims[0], n1 = prims[1], n2 = prims[2];
-  for (int k = 0; k < n; ++k) {
-    float4 q0 = n0, q1 = n1, q2 = n2;
-    if (k + 1 < n) { n0 = prims[3 * k + 3]; n1 = prims[3 * k + 4]; n2 = prims[3 * k + 5]; }
-    uint32_t idw = __float_as_uint(q0.w);
-    int id = (int)(idw & 0x7fffffffu);
-    float t = 0.0f; bool hit = false;
-    if (idw >> 31) {
-      hit = sphere_test(v3(q0), q1.y, o, d, &t);
-    } else {
-      // triangle.rs:69-100, same operations as tri_test(); the two __ballot tests only skip work
-      // that no lane of the wave needs (all lanes already rejected), they never change a result
-      V3 p0 = v3(q0), e1 = v3(q1), e2 = v3(q2);
-      V3 pv = cross(d, e2);
-      float det = dot(e1, pv);
-      bool ok = !(__builtin_fabsf(det) < kEps);
-      float invdet = 1.0f / det;
-      V3 tv = o - p0;
-      float u = dot(tv, pv) * invdet;
-      ok = ok && !(u < 0.0f || u > 1.0f);
-      if (__ballot(ok) != 0) {
-        V3 qv = cross(tv, e1);
-        float v = dot(d, qv) * invdet;
-        ok = ok && !(v < 0.0f || u + v > 1.0f);
-        if (__ballot(ok) != 0) {
-          t = dot(e2, qv) * invdet;
-          hit = ok && !(t < kEps);
-        }
-      }
-    }
-    if (SHADOW) {
-      float diff = t - dist;
-      if (hit && diff < -kEps) res.occluded = true;
-      hit = hit && !(diff > kEps);
-      if (__ballot(!res.occluded) == 0) break;               // every lane already knows it is occluded
-    }
-    if (hit && (t < res.t || (t == res.t && id < res.prim))) { res.t = t; res.prim = id; }
+  TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = (uint32_t)n;
+  // constant address space: uniform loads from it are always scalar (s_load), whatever the alias analysis thinks
+  const ConstRow* rows = (const ConstRow*)prims;
+  float4 a0 = row4(rows[0]), a1 = row4(rows[1]), a2 = row4(rows[2]);
+  for (int k = 0; k < n; k += 2) {
+    const ConstRow* nx = rows + 3 * k;
+    float4 b0 = row4(nx[3]), b1 = row4(nx[4]), b2 = row4(nx[5]);    // unconditional: the array is padded by two primitives
+    if (flat_test<SHADOW>(a0, a1, a2, o, d, dist, res)) break;
+    if (k + 1 >= n) break;
+    sgpr_pin(b0, b1, b2);                                           // first use of set B: the wait for its s_loads lands here
+    a0 = row4(nx[6]); a1 = row4(nx[7]); a2 = row4(nx[8]);
+    if (flat_test<SHADOW>(b0, b1, b2, o, d, dist, res)) break;
+    sgpr_pin(a0, a1, a2);
   }
-  res.tests = (uint32_t)n;
   return res;
 }
 
@@ -550,7 +589,10 @@ LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float
   // first k with roulette <= cumulative area (the host accumulates in the reference's order)
   int n = sc.n_emitters;
   if (n <= 8) {
-    while (k < n - 1 && !(roulette <= sc.emit[3 * k + 2].w)) ++k;
+    // the cumulative areas are nondecreasing, so "first k with roulette <= cum[k]" is a count; the rows are
+    // read with wave-uniform indices from the constant address space (s_load), no dependent vector loads
+    const ConstRow* er = (const ConstRow*)sc.emit;
+    for (int j = 0; j < n - 1; ++j) k += !(roulette <= er[3 * j + 2].w) ? 1 : 0;
   } else {
     int lo = 0, hi = n - 1;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (roulette <= sc.emit[3 * mid + 2].w) hi = mid; else lo = mid + 1; }
@@ -586,7 +628,7 @@ LR_DEV float russian_roulette(float init, int d, const DevParams& rp) {   // sce
 // ------------------------------------------------------------------------------------------
 // work items: item = chunk * n_pix + pixel rank; pixel rank -> (x, y) through the tile list
 // ------------------------------------------------------------------------------------------
-LR_DEV uint32_t item_pixel(const DevState& st, const DevCamera& cam, uint32_t rank) {
+LR_DEV uint32_t rank_to_pixel(const DevState& st, const DevCamera& cam, uint32_t rank) {
   int lo = 0, hi = st.n_tiles - 1;
   while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (st.tile_prefix[mid] <= rank) lo = mid; else hi = mid - 1; }
   int4 t = st.tiles[lo];
@@ -594,6 +636,8 @@ LR_DEV uint32_t item_pixel(const DevState& st, const DevCamera& cam, uint32_t ra
   uint32_t x = (uint32_t)t.x + off % (uint32_t)t.z, y = (uint32_t)t.y + off / (uint32_t)t.z;
   return y * (uint32_t)cam.res_w + x;
 }
+// the search runs once per pixel rank per render (k_rank_table); the path kernels read the table
+LR_DEV uint32_t item_pixel(const DevState& st, const DevCamera& cam, uint32_t rank) { (void)cam; return st.rank_pixel[rank]; }
 
 // Start the camera sample (pixel, sample) in `slot`.
 LR_DEV void start_sample(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, uint32_t pixel, uint32_t sample) {
@@ -839,11 +883,11 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
     float2 h = st.hit[slot];
     float t = h.x; int prim = __float_as_int(h.y);
     V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
-    float4 sh = sc.shade[prim];
+    const float4* rec = sc.shade + 4 * (size_t)prim;              // one 64-B record: no dependent second fetch for the material
+    float4 sh = rec[0];
+    Mat m; m.m0 = rec[1]; m.m1 = rec[2]; m.m2 = rec[3];
     uint32_t mw = __float_as_uint(sh.w);
     V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
-    uint32_t mi = mw & 0x7fffffffu;
-    Mat m; m.m0 = sc.mats[3 * mi]; m.m1 = sc.mats[3 * mi + 1]; m.m2 = sc.mats[3 * mi + 2];
     V3 out_ = -d;
     V3 emission = v3(m.m1);
     bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
@@ -895,12 +939,13 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
 LR_DEV void shadow_resolve(const DevScene& sc, const DevState& st, uint32_t slot, V3 o, V3 dir, const TraceResult& r) {
   if (!r.occluded && r.prim >= 0) {                                // scene.rs:127-131
     V3 pos = o + dir * r.t;
-    float4 sh = sc.shade[r.prim];
+    const float4* rec = sc.shade + 4 * (size_t)r.prim;
+    float4 sh = rec[0], em = rec[2];
     uint32_t mw = __float_as_uint(sh.w);
     V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
     float light_cos = dot(-dir, light_normal);
     if (light_cos > 0.0f) {                                        // scene.rs:133-139
-      V3 l_i = v3(sc.mats[3 * (mw & 0x7fffffffu) + 1]);           // emission of what was hit (scene.rs:144)
+      V3 l_i = v3(em);                                             // emission of what was hit (scene.rs:144)
       float4 w = st.sh_w[slot];
       float4 ra = st.rad[slot];
       V3 L = v3(ra) + v3(w) * l_i * light_cos;
@@ -1092,6 +1137,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   __shared__ uint32_t s_cnt[8];            // [0..5] shade lists, [6] shadow list
   __shared__ uint32_t s_retired;
   __shared__ uint32_t s_stat[ST_COUNT];
+  __shared__ uint8_t s_qid[kFlatMax];
   DevState st = gst;
   st.ray_o = lds4; st.ray_d = lds4 + kRSeg; st.thr = lds4 + 2 * kRSeg; st.rad = lds4 + 3 * kRSeg;
   st.sh_d = lds4 + 4 * kRSeg; st.sh_w = lds4 + 5 * kRSeg;
@@ -1102,6 +1148,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   uint16_t* shq = lists + 6 * kRSeg;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
+  if ((int)tid < sc.n_flat) s_qid[tid] = sc.prim_qid[tid];          // flat scenes: the BSDF id of a hit comes from LDS, not from an L2 round trip
   if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kRSeg, kRSeg); s_retired = 0; }   // first fill: one item per slot
   __syncthreads();
   for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
@@ -1134,7 +1181,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
         active = true;
         TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, nullptr);
         st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
-        qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
+        qid = r.prim < 0 ? kQMiss : (sc.n_flat > 0 ? (int)s_qid[r.prim] : (int)sc.prim_qid[r.prim]);
         n_seg += 1;
       }
       // a ray that left the scene is finished right here (sky lookup, fold, next camera sample): the
@@ -1194,6 +1241,11 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   stat_accumulate(&s_stat[ST_SKY], n_sky);
   __syncthreads();
   stat_flush(gst.stats, s_stat);
+}
+
+__global__ void __launch_bounds__(kBlock) k_rank_table(DevScene sc, DevState st) {
+  uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t rank = blockIdx.x * kBlock + threadIdx.x; rank < st.n_pix; rank += stride) st.rank_pixel[rank] = rank_to_pixel(st, sc.cam, rank);
 }
 
 __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, DevParams rp) {

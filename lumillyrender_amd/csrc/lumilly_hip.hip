@@ -66,7 +66,7 @@ struct LrScene {
   hipStream_t stream = nullptr;
   int n_cus = 0;
   // scene blob
-  DevBuf<float4> nodes, prims, shade, mats, emit, texels;
+  DevBuf<float4> nodes, prims, shade, emit, texels;
   DevBuf<uint8_t> prim_qid;
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
@@ -76,7 +76,7 @@ struct LrScene {
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
-  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix;
+  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel;
   DevBuf<uint4> pool;
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
@@ -115,7 +115,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // per-primitive shading rows + emitter table (objects.rs:19-24) in instance order
-  std::vector<float4> shade((size_t)np), emit;
+  std::vector<float4> shade((size_t)np * 4), emit;
   std::vector<uint8_t> qid((size_t)np);
   std::vector<float> area((size_t)np);
   for (int q = 0; q < kNumShadeQueues - 1; ++q) s.mat_present[q] = false;
@@ -128,12 +128,13 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       float e2[3] = {p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2]};
       float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
       float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-      shade[i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
+      shade[4 * i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
       area[i] = nrm * 0.5f;
     } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
-      shade[i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
+      shade[4 * i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
       area[i] = 4.0f * kPi * (p.v[3] * p.v[3]);
     } else fail(LR_EINVAL, "unknown primitive type");
+    for (int k = 0; k < 3; ++k) shade[4 * i + 1 + k] = mats[3 * (size_t)p.material + k];
     int mt = d.materials[p.material].type;
     qid[i] = (uint8_t)mt;
     s.mat_present[mt] = true;
@@ -166,11 +167,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // BVH nodes + primitives in leaf order
-  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3);
+  // + 2 rows of padding: the flat loop (traverse_flat) requests primitive k+1 and k+2 unconditionally
+  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3 + 6, make_float4(0, 0, 0, 0));
   s.bvh_build_ms = 0.0;
   bool built_on_device = false;
   if (device_bvh && np >= 2) {
-    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3);
+    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3 + 6);
     int height = 0; std::string err;
     int rc = lbvh_build(d.prims, np, d.camera.aperture_position, s.stream, s.nodes.p, s.prims.p, &height, &s.bvh_build_ms, err);
     if (rc != LR_OK) fail(rc, "device BVH build: " + err);
@@ -242,13 +244,13 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
 
   if (!built_on_device) { s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); }
   s.shade.upload(shade, s.stream);
-  s.mats.upload(mats, s.stream); s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
+  s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
   s.prim_qid.upload(qid, s.stream);
   HIP_OK(hipStreamSynchronize(s.stream));
 
   DevScene& v = s.dev;
   std::memset(&v, 0, sizeof(v));
-  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.mats = s.mats.p; v.emit = s.emit.p;
+  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.emit = s.emit.p;
   v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
   v.n_flat = (np > 0 && np <= kFlatMax) ? np : 0;
   v.n_emitters = (int)emitters.size(); v.emission_area = emission_area;
@@ -341,7 +343,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.pool.ensure(n_seg);
   s.counters.ensure(4);
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 8);
-  s.partial.ensure(n_items);
+  s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
     HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
@@ -359,7 +361,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.q_shade = s.q_shade.p; ds.c_shade = s.c_shade.p; ds.q_shadow = s.q_shadow.p; ds.c_shadow = s.c_shadow.p; ds.pool = s.pool.p;
   ds.next_item = s.counters.p; ds.n_retired = s.counters.p + 1;
   ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p;
-  ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size();
+  ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size(); ds.rank_pixel = s.rank_pixel.p;
   ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
   DevParams dp; dp.integrator = rp_in.integrator; dp.spp = rp_in.spp; dp.seed = rp_in.seed; dp.depth = rp_in.depth;
@@ -390,6 +392,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_seg * kBlock);
 
   Launcher L{s, profile};
+  if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, s.dev, ds);
   if (n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
@@ -514,9 +517,9 @@ int lr_scene_destroy(LrScene* s) {
   if (!s) return LR_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  s->nodes.release(); s->prims.release(); s->shade.release(); s->mats.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
+  s->nodes.release(); s->prims.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release();
+  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release();
   s->stats_dev.release(); s->film.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
