@@ -167,12 +167,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // BVH nodes + primitives in leaf order
-  // + 2 rows of padding: the flat loop (traverse_flat) requests primitive k+1 and k+2 unconditionally
-  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3 + 6, make_float4(0, 0, 0, 0));
+  // + 3 primitives of padding: the flat loop (traverse_flat) requests whole groups unconditionally
+  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3 + 9, make_float4(0, 0, 0, 0));
   s.bvh_build_ms = 0.0;
   bool built_on_device = false;
   if (device_bvh && np >= 2) {
-    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3 + 6);
+    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3 + 9);
     int height = 0; std::string err;
     int rc = lbvh_build(d.prims, np, d.camera.aperture_position, s.stream, s.nodes.p, s.prims.p, &height, &s.bvh_build_ms, err);
     if (rc != LR_OK) fail(rc, "device BVH build: " + err);
@@ -328,7 +328,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   bool resident = resident_lds <= 40 * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
-  const int resident_per_cu = std::max(1, std::min(5, (int)((160 * 1024) / (resident_lds + 512))));
+  const int resident_per_cu = std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : (1u << 20));
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
