@@ -60,7 +60,7 @@ LR_DEV bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   V3 pv = cross(d, e2);
   float det = dot(e1, pv);
   if (__builtin_fabsf(det) < kEps) return false;
-  float invdet = 1.0f / det;
+  float invdet = rcp_exact_mid(det);                  // == 1.0f / det, see lr_math.h
   V3 tv = o - p0;
   float u = dot(tv, pv) * invdet;
   if (u < 0.0f || u > 1.0f) return false;
@@ -247,7 +247,7 @@ LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, T
     V3 p0 = v3(q0), e1 = v3(q1), e2 = v3(q2);
     V3 pv = cross(d, e2);
     float det = dot(e1, pv);
-    float invdet = 1.0f / det;
+    float invdet = rcp_exact_mid(det);                  // == 1.0f / det, see lr_math.h
     V3 tv = o - p0;
     float u = dot(tv, pv) * invdet;
     bool ok = bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f));
@@ -272,7 +272,7 @@ LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, T
     res.occluded = res.occluded | (hit & bool(diff < -kEps));
     hit = hit & bool(!(diff > kEps));
   }
-  bool better = hit & (bool(t < res.t) | (bool(t == res.t) & bool(id < res.prim)));
+  bool better = hit & bool(t < res.t);                   // rows come in primitive-id order: the first of equal hits is the lowest id
   res.t = better ? t : res.t;
   res.prim = better ? id : res.prim;
   return SHADOW && __ballot(!res.occluded) == 0;
@@ -1094,12 +1094,16 @@ LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t b
   }
 }
 
+// The lists of one iteration are cut into 64-entry chunks and the chunks of ALL lists are dealt round-robin to the
+// four waves (*next_chunk carries the running chunk number from list to list): with one wave per list start, a
+// scene with five BSDFs of ~40 hits each would run its whole shade phase on wave 0.
 template <int MT>
 LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const DevParams& rp,
                                 const uint8_t* list, uint32_t n, uint8_t* shadow_list, uint32_t* shadow_cnt,
-                                uint8_t* finish_list, uint32_t* finish_cnt) {
-  for (uint32_t base = 0; base < n; base += kBlock) {
-    uint32_t i = base + threadIdx.x;
+                                uint8_t* finish_list, uint32_t* finish_cnt, uint32_t wave, uint32_t lane, uint32_t* next_chunk) {
+  const uint32_t chunks = (n + 63u) >> 6;
+  for (uint32_t c = (wave - *next_chunk) & (kBlock / 64 - 1); c < chunks; c += kBlock / 64) {
+    uint32_t i = c * 64u + lane;
     bool valid = i < n;
     uint32_t slot = valid ? list[i] : 0;
     VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
@@ -1111,6 +1115,7 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
     uint32_t idx = wave_reserve(shadow_cnt, v.has_shadow);
     if (v.has_shadow) shadow_list[idx] = (uint8_t)slot;
   }
+  *next_chunk += chunks;
 }
 
 constexpr int kPoolBatch = 64, kPoolLow = 24;
@@ -1142,6 +1147,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   uint8_t* shq = lists + 5 * kRSeg;
   uint8_t* finq = lists + 6 * kRSeg;
   const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
   if (tid < ST_COUNT) s_stat[tid] = 0;
   if (tid < 16) s_cnt2[tid >> 3][tid & 7] = 0;
   if ((int)tid < sc.n_flat) s_qid[tid] = sc.prim_qid[tid];          // flat scenes: the BSDF id of a hit comes from LDS, not from an L2 round trip
@@ -1216,11 +1222,12 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     // nobody draws work items in this phase, so the last thread (its wave has the least shade work: the lists fill
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
     if (tid == kBlock - 1) pool_step(st, &pl, kPoolLow, kPoolBatch);   // keeps a few iterations of draws; small batches keep the end-of-render tail short
-    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7]);
-    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7]);
-    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7]);
-    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7]);
-    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7]);
+    uint32_t next_chunk = 0;
+    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     LR_TICK(3)
     __syncthreads();
     LR_TICK(0)
@@ -1231,8 +1238,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     const uint32_t nsh = s_cnt[6], nfin = s_cnt[7];
     if (tid < 8) s_cnt_next[tid] = 0;                               // the other parity's counters are idle during this iteration
     const uint32_t wsh = (nsh + 63u) >> 6, wfin = (nfin + 63u) >> 6;
-    const uint32_t lane = tid & 63u;
-    for (uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6); v < wsh + wfin; v += kBlock / 64) {
+    for (uint32_t v = wave; v < wsh + wfin; v += kBlock / 64) {
       if (v < wsh) {
         uint32_t i = v * 64u + lane;
         if (i < nsh) {
@@ -1322,6 +1328,24 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const float* film, uint8_t*
       out[4 * (size_t)i] = c[0]; out[4 * (size_t)i + 1] = c[1]; out[4 * (size_t)i + 2] = c[2]; out[4 * (size_t)i + 3] = c[3];
     }
   }
+}
+
+// exhaustive check of rcp_exact_mid against the IEEE quotient: out[0..1] mismatch counts of the 2- and 3-step
+// variants over all finite d with biased exponent in [lo_exp, hi_exp], out[2..3] = one offending bit pattern each
+__global__ void k_selftest_rcp(uint32_t lo_exp, uint32_t hi_exp, unsigned long long* out) {
+  unsigned long long bad2 = 0, bad3 = 0;
+  uint32_t ex2 = 0, ex3 = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    uint32_t bits = (uint32_t)i, ex = (bits >> 23) & 0xffu;
+    if (ex < lo_exp || ex > hi_exp) continue;
+    float d = __uint_as_float(bits);
+    uint32_t want = __float_as_uint(1.0f / d);
+    if (__float_as_uint(rcp_exact_mid(d)) != want) { bad2 += 1; ex2 = bits; }
+    if (__float_as_uint(rcp_exact_mid3(d)) != want) { bad3 += 1; ex3 = bits; }
+  }
+  if (bad2) { atomicAdd(out, bad2); out[2] = ex2; }
+  if (bad3) { atomicAdd(out + 1, bad3); out[3] = ex3; }
 }
 
 // ---- diagnostics kernels (lr_selftest_*) ----------------------------------------------------------

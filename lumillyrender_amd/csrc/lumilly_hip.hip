@@ -66,7 +66,7 @@ struct LrScene {
   hipStream_t stream = nullptr;
   int n_cus = 0;
   // scene blob
-  DevBuf<float4> nodes, prims, shade, emit, texels;
+  DevBuf<float4> nodes, prims, flat, shade, emit, texels;
   DevBuf<uint8_t> prim_qid;
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
@@ -127,6 +127,10 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       float e1[3] = {p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2]};
       float e2[3] = {p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2]};
       float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      // the device's 1/det is the IEEE quotient only below 2^126 (lr_math.h rcp_exact_mid); |det| <= |e1| |e2| |d|
+      double l1 = std::sqrt((double)e1[0] * e1[0] + (double)e1[1] * e1[1] + (double)e1[2] * e1[2]);
+      double l2 = std::sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]);
+      if (!(l1 * l2 < 1.329227995784916e36)) fail(LR_EUNSUPPORTED, "triangle " + std::to_string(i) + ": |e1| |e2| >= 2^120 is outside the exact-arithmetic range of the device path");
       float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       shade[4 * i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
       area[i] = nrm * 0.5f;
@@ -167,12 +171,11 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // BVH nodes + primitives in leaf order
-  // + 3 primitives of padding: the flat loop (traverse_flat) requests whole groups unconditionally
-  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3 + 9, make_float4(0, 0, 0, 0));
+  std::vector<float4> nodes, prims((size_t)std::max(np, 1) * 3, make_float4(0, 0, 0, 0));
   s.bvh_build_ms = 0.0;
   bool built_on_device = false;
   if (device_bvh && np >= 2) {
-    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3 + 9);
+    s.nodes.ensure((size_t)(np - 1) * 4); s.prims.ensure((size_t)np * 3);
     int height = 0; std::string err;
     int rc = lbvh_build(d.prims, np, d.camera.aperture_position, s.stream, s.nodes.p, s.prims.p, &height, &s.bvh_build_ms, err);
     if (rc != LR_OK) fail(rc, "device BVH build: " + err);
@@ -243,6 +246,23 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   } else if (d.sky.type != LR_SKY_UNIFORM) fail(LR_EINVAL, "unknown sky type");
 
   if (!built_on_device) { s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); }
+  if (np > 0 && np <= kFlatMax) {
+    // small scenes are tested without a tree (traverse_flat): the same rows IN PRIMITIVE-ID ORDER, so that "first
+    // strictly nearer hit wins" is the lowest-id tie rule; padded by three primitives (the loop requests whole groups)
+    std::vector<float4> flat((size_t)np * 3 + 9, make_float4(0, 0, 0, 0));
+    for (int id = 0; id < np; ++id) {
+      const LrPrimitive& p = d.prims[id];
+      if (p.type == LR_PRIM_TRIANGLE) {
+        flat[3 * id] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
+        flat[3 * id + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
+        flat[3 * id + 2] = make_float4(p.v[6] - p.v[0], p.v[7] - p.v[1], p.v[8] - p.v[2], 0.0f);
+      } else {
+        flat[3 * id] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id | 0x80000000u));
+        flat[3 * id + 1] = make_float4(p.v[3], p.v[3] * p.v[3], 0.0f, 0.0f);
+      }
+    }
+    s.flat.upload(flat, s.stream);
+  }
   s.shade.upload(shade, s.stream);
   s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
   s.prim_qid.upload(qid, s.stream);
@@ -397,7 +417,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     HIP_OK(hipFuncSetAttribute((const void*)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.prims.p); });
+    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.flat.p); });
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {
@@ -413,8 +433,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p, spb_trace); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.prims.p, spb_trace); });
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.flat.p, spb_trace); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.flat.p, spb_trace); });
         if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp); });
@@ -422,8 +442,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp); });
         if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p, spb_shadow); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.prims.p, spb_shadow); });
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
         }
         L.iter++; S.iterations++;
       }
@@ -517,7 +537,7 @@ int lr_scene_destroy(LrScene* s) {
   if (!s) return LR_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  s->nodes.release(); s->prims.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
+  s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
   s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release();
   s->stats_dev.release(); s->film.release();
@@ -598,6 +618,18 @@ int lr_selftest_math(int device, int fn, const float* a, const float* b, float* 
     da.release(); db.release(); dout.release();
   })
 }
+int lr_selftest_rcp(int device, uint32_t lo_exp, uint32_t hi_exp, uint64_t* out4) {
+  LR_TRY({
+    if (!out4) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(device));
+    DevBuf<unsigned long long> d; d.ensure(4);
+    HIP_OK(hipMemset(d.p, 0, 32));
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(256 * 16), dim3(256), 0, 0, lo_exp, hi_exp, d.p);
+    HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out4, d.p, 32, hipMemcpyDeviceToHost));
+    d.release();
+  })
+}
 int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint32_t* sample, const uint32_t* block, float* out4, int n) {
   LR_TRY({
     if (!pixel || !sample || !block || !out4 || n < 0) fail(LR_EINVAL, "bad argument");
@@ -622,7 +654,7 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
     size_t lds = (size_t)s->stack_depth * kBlock * 4;
-    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, (const float4*)s->prims.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
+    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, (const float4*)s->flat.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -42,6 +42,7 @@ def lib():
     up = C.POINTER(C.c_uint32)
     l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
     l.lr_selftest_intersect.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
     return l
 
@@ -152,6 +153,14 @@ def selftest_rng(seed, pixel, sample, block, device=0):
     up = C.POINTER(C.c_uint32)
     _check(lib().lr_selftest_rng(device, seed, pixel.ctypes.data_as(up), sample.ctypes.data_as(up), block.ctypes.data_as(up), _fptr(out), pixel.size))
     return out
+
+
+def selftest_rcp(lo_exp, hi_exp, device=0):
+    """Exhaustive check of the device's five-instruction exact reciprocal against IEEE 1/d over every float whose
+    biased exponent lies in [lo_exp, hi_exp]: returns (mismatches of the 2-step form, of the 3-step form, example bits)."""
+    out = (C.c_uint64 * 4)()
+    _check(lib().lr_selftest_rcp(device, lo_exp, hi_exp, out))
+    return int(out[0]), int(out[1]), (int(out[2]), int(out[3]))
 
 
 def stats_dict(s):

@@ -98,6 +98,16 @@ def _random_rays(desc, n, seed):
     return o, d.astype(np.float32)
 
 
+def test_fast_reciprocal_is_ieee_exact(dev):
+    """The five-instruction 1/det of the triangle test (lr_math.h rcp_exact_mid) against the compiler's IEEE quotient
+    on EVERY float with a biased exponent in 1..252: 4.2e9 bit patterns, all the device code can ever feed it
+    (lr_scene_create refuses triangles with |e1| |e2| >= 2^120)."""
+    bad2, _bad3, example = dev.selftest_rcp(1, 252)
+    assert bad2 == 0, f"reciprocal differs from IEEE for bits {example[0]:#x}"
+    # outside that range the short form is NOT the IEEE quotient, which is why the range is enforced
+    assert dev.selftest_rcp(0, 0)[0] > 0 and dev.selftest_rcp(253, 254)[0] > 0
+
+
 @pytest.mark.parametrize("name", ["cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"])
 def test_closest_hit_matches_brute_force(dev, oracle, name):
     desc = load(name, 64, 64)
@@ -432,6 +442,12 @@ def test_device_api_rejects_bad_input(dev):
     bad = abi.LrSceneDesc.from_buffer_copy(d)
     bad.prims = C.cast(prims, C.POINTER(abi.LrPrimitive))
     assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
+    # a triangle whose edges leave the range in which the device's 1/det is proven to be the IEEE quotient
+    tri = next(i for i in range(d.n_prims) if d.prims[i].type == abi.LR_PRIM_TRIANGLE)
+    C.memmove(prims, d.prims, C.sizeof(prims))
+    for k in (3, 6):
+        prims[tri].v[k] = 3.0e30
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EUNSUPPORTED and b"2^120" in lib.lr_last_error()
     # render-time errors leave the scene usable
     scene = dev.Scene(desc)
     for kw in ({"spp": 0}, {"spp": -3}):
