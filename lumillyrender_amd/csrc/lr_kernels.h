@@ -344,15 +344,46 @@ LR_DEV float signed_mod(float base, float module) {                    // lamber
   if (base > 0.0f) return det_fmod_pos(base, module);
   return module - det_fmod_pos(-base, module);
 }
-LR_DEV float checker(float u, float v) {                               // lambert.rs:66-90 (grey level)
-  const float lw = 2.0f, li = 150.0f, sw = 1.0f, si = 30.0f, cw = 150.0f, ci = 300.0f;
-  float lu = signed_mod(u, li), lv = signed_mod(v, li);
-  float su = signed_mod(u, si), sv = signed_mod(v, si);
-  float cu = signed_mod(u, ci), cv = signed_mod(v, ci);
+LR_DEV float checker_level(float lu, float lv, float su, float sv, float cu, float cv) {   // lambert.rs:72-90
+  const float lw = 2.0f, sw = 1.0f, cw = 150.0f;
   if (lu < lw || lv < lw) return 0.5f;
   else if (su < sw || sv < sw) return 0.6f;
   else if ((cu < cw || cv < cw) && !(cu < cw && cv < cw)) return 0.8f;
   return 1.0f;
+}
+// the general form: six independent remainders, any magnitude (kept out of line: it only runs for |u|, |v| >= 2^24)
+__attribute__((noinline)) LR_DEV float checker_general(float u, float v) {
+  const float li = 150.0f, si = 30.0f, ci = 300.0f;
+  return checker_level(signed_mod(u, li), signed_mod(v, li), signed_mod(u, si), signed_mod(v, si), signed_mod(u, ci), signed_mod(v, ci));
+}
+// f = |x| mod 300, then mod 150 and mod 30 FROM it: 300 = 2 * 150 and 150 = 5 * 30, every remainder is exactly
+// representable and every step below is an exact operation (Sterbenz subtraction, small-integer products), so the
+// three values are the same bits as three independent fmods -- two full remainders per call instead of six, and
+// no per-remainder fallback branch in the shading code.
+LR_DEV void mods_300_150_30(float ax, float* m300, float* m150, float* m30) {
+  float q = __builtin_floorf(ax * (1.0f / 300.0f));
+  float r = ax - q * 300.0f;                       // exact for ax < 2^24 whether q is right or one off
+  r = r < 0.0f ? r + 300.0f : r;
+  r = r >= 300.0f ? r - 300.0f : r;
+  float h = r >= 150.0f ? r - 150.0f : r;
+  float q3 = __builtin_floorf(h * (1.0f / 30.0f));
+  float t = h - q3 * 30.0f;
+  t = t < 0.0f ? t + 30.0f : t;
+  t = t >= 30.0f ? t - 30.0f : t;
+  *m300 = r; *m150 = h; *m30 = t;
+}
+LR_DEV float checker(float u, float v) {                               // lambert.rs:66-90 (grey level)
+  float au = __builtin_fabsf(u), av = __builtin_fabsf(v);
+  if (__ballot(!(au < 16777216.0f && av < 16777216.0f)) != 0) return checker_general(u, v);
+  float u300, u150, u30, v300, v150, v30;
+  mods_300_150_30(au, &u300, &u150, &u30);
+  mods_300_150_30(av, &v300, &v150, &v30);
+  // signed_mod: base > 0 ? fmod(base, m) : m - fmod(-base, m)
+  bool up = u > 0.0f, vp = v > 0.0f;
+  float lu = up ? u150 : 150.0f - u150, lv = vp ? v150 : 150.0f - v150;
+  float su = up ? u30 : 30.0f - u30, sv = vp ? v30 : 30.0f - v30;
+  float cu = up ? u300 : 300.0f - u300, cv = vp ? v300 : 300.0f - v300;
+  return checker_level(lu, lv, su, sv, cu, cv);
 }
 LR_DEV float ggx_g(float alpha, V3 v, V3 n) {                          // ggx.rs:27-32
   float a2 = alpha * alpha;

@@ -68,6 +68,28 @@ def test_device_math_bit_exact(dev, oracle):
     assert np.array_equal(dev.selftest_math(8, p), np.sqrt(p))
 
 
+def test_device_checker_matches_oracle(dev, oracle):
+    """lambert.rs:58-90 on the device (two shared exact remainders per coordinate) against the oracle's six fmods:
+    random points, exact multiples of the periods, one-ulp neighbours of every band edge, both signs, zeros,
+    and magnitudes beyond 2^24 (the general path)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    edges = np.array([0, 1, 2, 30, 31, 32, 150, 151, 152, 300, 450, 600, 4500, 16777215, 16777216, 3.0e8], dtype=np.float32)
+    near = np.concatenate([edges, np.nextafter(edges, np.float32(np.inf)), np.nextafter(edges, np.float32(-np.inf))])
+    pts = np.concatenate([near, -near, (rng.random(3000) * 2000 - 1000).astype(np.float32), np.array([-0.0], dtype=np.float32),
+                          (rng.integers(-40, 40, 400) * 30).astype(np.float32), (rng.random(200) * 6e7 - 3e7).astype(np.float32)])
+    u = rng.permutation(pts).astype(np.float32)
+    v = rng.permutation(pts).astype(np.float32)
+    got = dev.selftest_math(9, u, v)
+    out = (C.c_float * 3)()
+    want = np.empty_like(got)
+    for i, (a, b) in enumerate(zip(u, v)):
+        oracle.lib().lr_oracle_checker(float(a), float(b), out)
+        want[i] = out[0]
+    assert np.array_equal(got, want)
+    assert set(np.unique(got)) == {np.float32(0.5), np.float32(0.6), np.float32(0.8), np.float32(1.0)}
+
+
 def test_device_rng_bit_exact(dev, oracle):
     rng = np.random.default_rng(2)
     px = rng.integers(0, 2 ** 22, 512, dtype=np.uint32)
