@@ -1,8 +1,10 @@
 // lr_device.h -- HBM layouts shared by the kernels and the C ABI implementation.
 //
 // Scene blob (read-only, replicated per GPU; DESIGN.md "data layout in HBM"):
-//   nodes   4 x float4 per BVH node (64 B): x-row, y-row, z-row = {l.min, l.max, r.min, r.max}, then
-//           {child0, child1, -, -} as int bits.  child >= 0 inner, child < 0 leaf ~c = first<<3 | count.
+//   nodes   8 x float4 per 4-wide BVH node (128 B, 112 used): {lo.x of child 0..3} {hi.x} {lo.y} {hi.y} {lo.z} {hi.z}
+//           {child 0..3 as int bits} {-}.  child >= 0 inner node, child < 0 leaf ~c = first<<3 | count,
+//           0x7fffffff = empty slot.  lr_scene_create collapses the binary tree of the description (or of the device
+//           LBVH build) into this form: one fetch per two binary levels.
 //   prims   3 x float4 per primitive (48 B) IN LEAF ORDER, so a leaf reads consecutive rows:
 //             triangle  {p0.xyz, id} {e1.xyz, -} {e2.xyz, -}     e1 = p1-p0, e2 = p2-p0 (triangle.rs:71-72)
 //             sphere    {c.xyz, id | 1<<31} {r, r*r, -, -} {-}
@@ -28,6 +30,7 @@
 namespace lr {
 
 constexpr int kBlock = 256;            // 4 waves of 64
+constexpr int kStackLdsMax = 31;       // traversal stack entries per lane kept in LDS by the streaming kernels
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
 constexpr int kFlatMax = 32;          // scenes up to this many primitives skip the tree
@@ -53,6 +56,11 @@ struct DevScene {
   const float4* texels;
   const uint8_t* prim_qid;             // per primitive id: shade queue (= material type)
   int   n_flat;                        // > 0: test all n_flat primitives with scalar loads instead of walking the tree
+  // traversal stack of one lane: entries [0, stack_lds) in LDS (entry e of thread t at [e * 256 + t]), deeper ones --
+  // rare with near-first order -- in stack_spill (HBM/L2, [(block * spill_depth + e - stack_lds) * 256 + t]).  The
+  // worst case of a 4-wide tree (3 pushes per level) would otherwise cap a CU at 3 workgroups.  Set per launch.
+  int   stack_lds, spill_depth;
+  uint32_t* stack_spill;
   int   n_emitters;
   float emission_area;
   int   sky_type;

@@ -129,44 +129,62 @@ LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
 
 // (stack entries carry no entry distance: a stale subtree costs one node fetch whose boxes then fail
 //  the cull test, but 4 B per entry instead of 8 doubles the workgroups an LDS-bound CU can hold)
+LR_DEV void stack_store(const DevScene& sc, uint32_t* stk_n, int e, uint32_t v) {
+  if (e < sc.stack_lds) stk_n[e * kBlock + threadIdx.x] = v;
+  else sc.stack_spill[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x] = v;
+}
+LR_DEV uint32_t stack_load(const DevScene& sc, const uint32_t* stk_n, int e) {
+  if (e < sc.stack_lds) return stk_n[e * kBlock + threadIdx.x];
+  return sc.stack_spill[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x];
+}
 template <bool SHADOW>
-LR_DEV bool trav_pop(Trav<SHADOW>& s, const uint32_t* stk_n) {
-  if (s.sp > 0) { --s.sp; s.cur = (int)stk_n[s.sp * kBlock + threadIdx.x]; return true; }
+LR_DEV bool trav_pop(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n) {
+  if (s.sp > 0) { --s.sp; s.cur = (int)stack_load(sc, stk_n, s.sp); return true; }
   return false;
 }
 
-// One inner node (s.cur >= 0): test both child boxes, descend into the nearer one.  false = ray finished.
+// One inner node (s.cur >= 0) of the 4-wide tree: one 112-B fetch tests four child boxes, the hit children are
+// ordered by entry distance (5-comparator network), the nearest becomes the next node and the others go on the
+// stack far-first.  Half the dependent fetch rounds of a binary tree -- the traversal is latency-bound, not
+// bandwidth-bound.  false = ray finished.
+constexpr int kEmptyChild = 0x7fffffff;
+LR_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
+  bool sw = kb < ka;
+  float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+  int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+  ka = k0; kb = k1; ra = r0; rb = r1;
+}
 template <bool SHADOW>
 LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
-  const float4* n = sc.nodes + 4 * (size_t)s.cur;
-  float4 nx = n[0], ny = n[1], nz = n[2], nc = n[3];
-  s.visits += 2;
-  float lmin, lmax, rmin, rmax;
+  const float4* n = sc.nodes + 8 * (size_t)s.cur;
+  float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5], rc = n[6];
+  s.visits += 4;
+  float k0, k1, k2, k3;
+  int r0 = __float_as_int(rc.x), r1 = __float_as_int(rc.y), r2 = __float_as_int(rc.z), r3 = __float_as_int(rc.w);
   {
 #pragma clang fp contract(fast)
-    float a0 = __builtin_fmaf(nx.x, s.ix, s.ox), a1 = __builtin_fmaf(nx.y, s.ix, s.ox);
-    float b0 = __builtin_fmaf(ny.x, s.iy, s.oy), b1 = __builtin_fmaf(ny.y, s.iy, s.oy);
-    float c0 = __builtin_fmaf(nz.x, s.iz, s.oz), c1 = __builtin_fmaf(nz.y, s.iz, s.oz);
-    lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f));
-    lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull));
-    float d0 = __builtin_fmaf(nx.z, s.ix, s.ox), d1 = __builtin_fmaf(nx.w, s.ix, s.ox);
-    float e0 = __builtin_fmaf(ny.z, s.iy, s.oy), e1 = __builtin_fmaf(ny.w, s.iy, s.oy);
-    float f0 = __builtin_fmaf(nz.z, s.iz, s.oz), f1 = __builtin_fmaf(nz.w, s.iz, s.oz);
-    rmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, d1), __builtin_fminf(e0, e1)), __builtin_fmaxf(__builtin_fminf(f0, f1), 0.0f));
-    rmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d0, d1), __builtin_fmaxf(e0, e1)), __builtin_fminf(__builtin_fmaxf(f0, f1), s.cull));
+    const float inf = __builtin_inff();
+#define LR_SLAB(K, C, R)                                                                                         \
+    {                                                                                                            \
+      float a0 = __builtin_fmaf(lox.C, s.ix, s.ox), a1 = __builtin_fmaf(hix.C, s.ix, s.ox);                      \
+      float b0 = __builtin_fmaf(loy.C, s.iy, s.oy), b1 = __builtin_fmaf(hiy.C, s.iy, s.oy);                      \
+      float c0 = __builtin_fmaf(loz.C, s.iz, s.oz), c1 = __builtin_fmaf(hiz.C, s.iz, s.oz);                      \
+      float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f)); \
+      float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull)); \
+      K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
+    }
+    LR_SLAB(k0, x, r0) LR_SLAB(k1, y, r1) LR_SLAB(k2, z, r2) LR_SLAB(k3, w, r3)
+#undef LR_SLAB
+    int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
+    if (n_hit == 0) return trav_pop<SHADOW>(sc, s, stk_n);
+    order2(k0, r0, k1, r1); order2(k2, r2, k3, r3); order2(k0, r0, k2, r2); order2(k1, r1, k3, r3); order2(k1, r1, k2, r2);
+    if (n_hit == 4) { stack_store(sc, stk_n, s.sp, (uint32_t)r3); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 2, (uint32_t)r1); }
+    else if (n_hit == 3) { stack_store(sc, stk_n, s.sp, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r1); }
+    else if (n_hit == 2) { stack_store(sc, stk_n, s.sp, (uint32_t)r1); }
+    s.sp += n_hit - 1;
+    s.cur = r0;
   }
-  bool hl = lmin <= lmax, hr = rmin <= rmax;
-  int cl = __float_as_int(nc.x), cr = __float_as_int(nc.y);
-  if (hl && hr) {
-    bool swap = rmin < lmin;
-    stk_n[s.sp * kBlock + threadIdx.x] = (uint32_t)(swap ? cl : cr);
-    ++s.sp;
-    s.cur = swap ? cr : cl;
-    return true;
-  }
-  if (hl) { s.cur = cl; return true; }
-  if (hr) { s.cur = cr; return true; }
-  return trav_pop<SHADOW>(s, stk_n);
+  return true;
 }
 
 // One leaf (s.cur < 0): run the primitive tests of its range.  false = ray finished.
@@ -191,7 +209,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
     }
     if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; s.cull = t; }
   }
-  return trav_pop<SHADOW>(s, stk_n);
+  return trav_pop<SHADOW>(sc, s, stk_n);
 }
 
 // A burst of traversal for the lanes with `go` set (while-while: the wave first descends inner nodes

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -76,7 +77,7 @@ struct LrScene {
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
-  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel;
+  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill;
   DevBuf<uint4> pool;
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
@@ -90,6 +91,53 @@ struct LrScene {
 };
 
 namespace {
+
+// Binary tree (4 float4 per node: x/y/z rows {l.min, l.max, r.min, r.max}, {child0, child1}) -> 4-wide tree of
+// lr_device.h.  A node adopts its grandchildren: starting from its two children, the inner child with the largest
+// surface area is replaced by its own two children until four slots are filled.  Leaves keep their encoding.
+// Returns the worst-case traversal stack need (sum over a root-to-leaf path of children - 1).
+struct Wide4Builder {
+  const std::vector<float4>& in;
+  std::vector<float4>& out;
+  struct Cand { float lo[3], hi[3]; int ref; };
+  static float area(const Cand& c) {
+    float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+  void children(int node, Cand* two) const {
+    const float4 x = in[4 * (size_t)node], y = in[4 * (size_t)node + 1], z = in[4 * (size_t)node + 2], c = in[4 * (size_t)node + 3];
+    two[0] = Cand{{x.x, y.x, z.x}, {x.y, y.y, z.y}, __builtin_bit_cast(int, c.x)};
+    two[1] = Cand{{x.z, y.z, z.z}, {x.w, y.w, z.w}, __builtin_bit_cast(int, c.y)};
+  }
+  int build(int node, int* need_out) {
+    const size_t me = out.size() / 8;
+    out.resize(out.size() + 8, make_float4(0, 0, 0, 0));
+    Cand c[4]; int n = 2;
+    children(node, c);
+    while (n < 4) {
+      int pick = -1; float best = -1.0f;
+      for (int k = 0; k < n; ++k) if (c[k].ref >= 0 && area(c[k]) > best) { best = area(c[k]); pick = k; }
+      if (pick < 0) break;
+      Cand two[2]; children(c[pick].ref, two);
+      c[pick] = two[0]; c[n++] = two[1];
+    }
+    int need = 0;
+    float rows[7][4];
+    for (int k = 0; k < 4; ++k) {
+      int ref = kEmptyChild;
+      if (k < n) {
+        ref = c[k].ref;
+        if (ref >= 0) { int sub = 0; ref = build(ref, &sub); need = std::max(need, n - 1 + sub); }
+        else need = std::max(need, n - 1);
+      }
+      for (int a = 0; a < 3; ++a) { rows[2 * a][k] = k < n ? c[k].lo[a] : 0.0f; rows[2 * a + 1][k] = k < n ? c[k].hi[a] : 0.0f; }
+      rows[6][k] = __builtin_bit_cast(float, ref);
+    }
+    for (int r = 0; r < 7; ++r) out[me * 8 + r] = make_float4(rows[r][0], rows[r][1], rows[r][2], rows[r][3]);
+    *need_out = need;
+    return (int)me;
+  }
+};
 
 void pack_scene(LrScene& s, const LrSceneDesc& d) {
   if (d.abi_version != LR_ABI_VERSION) fail(LR_EINVAL, "LrSceneDesc.abi_version mismatch");
@@ -245,7 +293,23 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     for (size_t i = 0; i < n; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
   } else if (d.sky.type != LR_SKY_UNIFORM) fail(LR_EINVAL, "unknown sky type");
 
-  if (!built_on_device) { s.nodes.upload(nodes, s.stream); s.prims.upload(prims, s.stream); }
+  {
+    // 4-wide nodes for the device (the binary tree of the description, or the one the LBVH kernels just wrote)
+    if (built_on_device) {
+      nodes.resize((size_t)(np - 1) * 4);
+      HIP_OK(hipMemcpyAsync(nodes.data(), s.nodes.p, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
+      HIP_OK(hipStreamSynchronize(s.stream));
+    }
+    std::vector<float4> wide;
+    wide.reserve(nodes.size());
+    int need = 0;
+    Wide4Builder{nodes, wide}.build(0, &need);
+    if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
+    s.stack_depth = need + 1;
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes, stack need %d\n", nodes.size() / 4, wide.size() / 8, need);
+    s.nodes.upload(wide, s.stream);
+    if (!built_on_device) s.prims.upload(prims, s.stream);
+  }
   if (np > 0 && np <= kFlatMax) {
     // small scenes are tested without a tree (traverse_flat): the same rows IN PRIMITIVE-ID ORDER, so that "first
     // strictly nearer hit wins" is the lowest-id tie rule; padded by three primitives (the loop requests whole groups)
@@ -315,6 +379,12 @@ struct Launcher {
   }
 };
 
+// LR_STACK_LDS=<n> (diagnostic): keep only n stack entries per lane in LDS so that tests reach the spill path
+int stack_lds_limit() {
+  if (const char* e = std::getenv("LR_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= kStackLdsMax) return v; }
+  return kStackLdsMax;
+}
+
 void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, int n_tiles) {
   if (rp_in.spp <= 0) fail(LR_EINVAL, "spp must be positive");
   if (rp_in.integrator != LR_INTEGRATOR_PT && rp_in.integrator != LR_INTEGRATOR_PT_DIRECT) fail(LR_EINVAL, "unknown integrator");
@@ -343,7 +413,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t n_items = (uint32_t)n_items64;
   const bool count = (rp_in.flags & LR_FLAG_COUNT) != 0;
   // pipeline: resident (one launch, path state in LDS) when two workgroups fit a CU's 160 KB of LDS
-  const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 4;
+  const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 4;   // resident: the whole stack in LDS
   const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
   bool resident = resident_lds <= 40 * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
@@ -395,9 +465,17 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
-  const size_t lds = (size_t)s.stack_depth * kBlock * 4;
+  // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (5 workgroups of 31 KB per CU, the
+  // VGPR-limited occupancy), the rest of the worst case in a spill buffer that near-first traversal rarely reaches
+  const int stack_in_lds = resident ? s.stack_depth : std::min(s.stack_depth, stack_lds_limit());
+  const size_t lds = (size_t)stack_in_lds * kBlock * 4;
   const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
   const void* kshadow = count ? (const void*)k_shadow<true> : (const void*)k_shadow<false>;
+  if (lds > 156 * 1024) fail(LR_EUNSUPPORTED, "BVH too deep: the per-lane traversal stack does not fit the CU's LDS");
+  if (lds > 48 * 1024) {
+    HIP_OK(hipFuncSetAttribute(ktrace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute(kshadow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   const int g_trace = grid_for(ktrace, s.n_cus, lds, n_seg * kBlock);
   const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
   const uint32_t spb_trace = std::min<uint32_t>(kMaxGroup, (n_seg + g_trace - 1) / g_trace);     // segments per workgroup pass
@@ -411,17 +489,23 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_seg * kBlock);
   g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_seg * kBlock);
 
+  DevScene dsc = s.dev;
+  dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
+  if (dsc.spill_depth > 0) {
+    s.stack_spill.ensure((size_t)std::max(g_trace, g_shadow) * dsc.spill_depth * kBlock);
+    dsc.stack_spill = s.stack_spill.p;
+  }
   Launcher L{s, profile};
-  if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, s.dev, ds);
+  if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
   if (n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     HIP_OK(hipFuncSetAttribute((const void*)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, s.dev, ds, dp, mt_mask, (const float4*)s.flat.p); });
+    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {
-    L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, s.dev, ds, dp); });
+    L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, dsc, ds, dp); });
     const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
     const int kCheck = 8;
     int batch = 0;
@@ -433,17 +517,17 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.flat.p, spb_trace); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, s.dev, ds, (const float4*)s.flat.p, spb_trace); });
-        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, s.dev, ds, dp); });
-        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, s.dev, ds, dp); });
-        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, s.dev, ds, dp); });
-        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, s.dev, ds, dp); });
-        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, s.dev, ds, dp); });
-        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, s.dev, ds, dp); });
+        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, dsc, ds, (const float4*)s.flat.p, spb_trace); });
+        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, dsc, ds, (const float4*)s.flat.p, spb_trace); });
+        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, dsc, ds, dp); });
+        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, dsc, ds, dp); });
+        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, dsc, ds, dp); });
+        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, dsc, ds, dp); });
+        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, dsc, ds, dp); });
+        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, dsc, ds, dp); });
         if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, s.dev, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
+          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, dsc, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
+          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, dsc, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
         }
         L.iter++; S.iterations++;
       }
@@ -462,7 +546,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   }
   if (n_pix > 0) {
     int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, n_pix);
-    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, s.dev, ds, dp); });
+    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, dsc, ds, dp); });
   }
   HIP_OK(hipEventRecord(s.t_end, st));
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
@@ -539,7 +623,7 @@ int lr_scene_destroy(LrScene* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release();
+  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
   s->stats_dev.release(); s->film.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
@@ -653,8 +737,13 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
-    size_t lds = (size_t)s->stack_depth * kBlock * 4;
-    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, s->dev, (const float4*)s->flat.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
+    const int in_lds = std::min(s->stack_depth, stack_lds_limit());
+    size_t lds = (size_t)in_lds * kBlock * 4;
+    DevScene dsc = s->dev;
+    dsc.stack_lds = in_lds; dsc.spill_depth = s->stack_depth - in_lds; dsc.stack_spill = nullptr;
+    if (dsc.spill_depth > 0) { s->stack_spill.ensure((size_t)((n + kBlock - 1) / kBlock) * dsc.spill_depth * kBlock); dsc.stack_spill = s->stack_spill.p; }
+    if (lds > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void*)k_selftest_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, dsc, (const float4*)s->flat.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -416,6 +416,27 @@ def test_bvh_path_on_a_small_scene(dev, oracle):
     scene.close()
 
 
+def test_traversal_stack_spill_path(dev, oracle, monkeypatch):
+    """The streaming kernels keep 31 stack entries per lane in LDS and the rest of the 4-wide tree's worst case in a
+    spill buffer.  With LR_STACK_LDS=2 nearly every push goes through the spill path: same closest hits, same film."""
+    from lumillyrender_amd import abi
+    desc = load("mesh-box.toml", 64, 48)
+    scene = dev.Scene(desc)
+    rng = np.random.default_rng(11)
+    o = np.tile(np.array(desc.desc.camera.aperture_position, dtype=np.float32), (4096, 1))
+    d = rng.standard_normal((4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = desc.render_params(spp=4, seed=3, flags=abi.LR_FLAG_STREAMING)
+    prim0, t0 = scene.intersect(o, d)
+    img0 = scene.render(p)
+    monkeypatch.setenv("LR_STACK_LDS", "2")
+    prim1, t1 = scene.intersect(o, d)
+    img1 = scene.render(p)
+    assert np.array_equal(prim0, prim1) and np.array_equal(t0, t1)
+    assert np.array_equal(img0, img1)
+    scene.close()
+
+
 def test_device_film_output_stage(dev, tmp_path):
     """quantisation on the device (main.rs:171-173 gamma + truncation; img.rs:40-50 RGBE)
     against the host writers, which are pinned on CPU by tests/test_host_loader.py."""
