@@ -129,7 +129,7 @@ def main():
         params = desc.render_params(spp=spp, seed=i, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=flags, path_slots=args.slots)
         scene.render(params, tiles, n_tiles, out=canvas)      # blocks until the film tiles are on the host
         st = scene.stats()
-        multigpu.gather_film(canvas, dist, dst=0, group=host_group)              # host gather of the disjoint tiles (gloo)
+        multigpu.gather_tiles(canvas, W, H, args.tile, dist, dst=0, group=host_group)   # host gather of each rank's packed tiles (gloo)
         return st
 
     for i in range(args.warmup):

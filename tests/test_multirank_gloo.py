@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, packed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,7 +37,10 @@ def _worker(rank, world, port, out_path):
     mine = (film != 0).any(axis=2).sum()
     counts = torch.tensor([int(mine)])
     dist.all_reduce(counts)
-    multigpu.gather_film(film, dist, dst=0)
+    if packed:
+        multigpu.gather_tiles(film, W, H, TILE, dist, dst=0)
+    else:
+        multigpu.gather_film(film, dist, dst=0)
     if rank == 0:
         np.save(out_path, film)
         assert int(counts.item()) <= W * H
@@ -45,10 +48,10 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_render_equals_single_rank(tmp_path, world):
+@pytest.mark.parametrize("world,packed", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_render_equals_single_rank(tmp_path, world, packed):
     out_path = str(tmp_path / "film.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_path, packed), nprocs=world, join=True)
     from lumillyrender_amd import host
     from oracle import binding as oracle
     desc = host.Description(scene_path("cbox-spheres.toml"))
