@@ -42,7 +42,8 @@ def lib():
     up = C.POINTER(C.c_uint32)
     l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
     l.lr_selftest_intersect.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
-    l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    if hasattr(l, "lr_selftest_rcp"):                      # diagnostics entry point; older builds (tools/sweep.sh) lack it
+        l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
     return l
 
