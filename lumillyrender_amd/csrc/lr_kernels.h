@@ -1114,16 +1114,18 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
 }
 
 // ==========================================================================================
-// Resident pipeline: ONE launch for the whole render.  A workgroup owns one 512-slot segment from the
-// first camera sample to its last retired slot and keeps the segment's whole path state in LDS
-// (ray, hit, throughput, radiance, chunk sum, shadow record: 120 B x 512 = 60 KB, two workgroups per
-// CU).  The stages of the streaming pipeline survive as PHASES separated by workgroup barriers:
-//   trace (all live slots, compaction into per-BSDF lists with __ballot / mbcnt prefix sums)
-//   -> shade<BSDF> per list (regeneration from the segment's item pool) -> shadow list.
-// Segments never exchange data (only the global item dispenser and the chunk-sum array are shared), so
-// there is no grid barrier and no path-state traffic to HBM at all.  Used when the LDS budget allows
-// (small traversal stacks); results are bit-identical to the streaming pipeline (same device
-// functions, same RNG keys, same chunk order).
+// Resident pipeline: ONE launch for the whole render.  A workgroup owns 256 path slots from the first camera
+// sample to its last retired slot and keeps their whole path state in LDS (six 16-B rows per slot: ray origin,
+// direction, throughput, radiance, shadow direction, shadow weight -- the hit record borrows the shadow-weight row
+// between trace and shade -- plus seven byte lists: 25.75 KB, six workgroups per CU).  The stages of the streaming
+// pipeline survive as PHASES separated by three workgroup barriers per iteration:
+//   1 trace all live slots, __ballot / mbcnt compaction into per-BSDF lists, misses onto the finish list
+//   2 shade<BSDF> per list (chunks dealt round-robin to the waves), roulette deaths onto the finish list, pool top-up
+//   3 shadow list, and on the waves it leaves idle the finish pass (fold, next work item, next camera sample)
+// Workgroups never exchange data (only the global item dispenser and the chunk-sum array are shared), so there is
+// no grid barrier and no path-state traffic to HBM at all.  Used when the LDS budget allows (flat scenes, shallow
+// trees); results are bit-identical to the streaming pipeline (same device functions, same RNG keys, same
+// chunk order).
 // ==========================================================================================
 LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t batch) {
   uint32_t t0 = pl->taken < pl->a0 ? pl->taken : pl->a0;

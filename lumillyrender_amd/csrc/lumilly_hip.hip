@@ -412,7 +412,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
   const uint32_t n_items = (uint32_t)n_items64;
   const bool count = (rp_in.flags & LR_FLAG_COUNT) != 0;
-  // pipeline: resident (one launch, path state in LDS) when two workgroups fit a CU's 160 KB of LDS
+  // pipeline: resident (one launch, path state in LDS) when state + traversal stack stay under 40 KB per workgroup
+  // (>= 4 workgroups per CU; 6 for flat scenes), streaming otherwise
   const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 4;   // resident: the whole stack in LDS
   const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
   bool resident = resident_lds <= 40 * 1024 && !count;
