@@ -93,6 +93,7 @@ struct DevState {
   uint32_t* rank_pixel;                // n_pix: film pixel of every pixel rank (k_rank_table), one load instead of a search per work item
   int n_tiles;
   uint32_t n_slots, n_seg, n_pix, n_chunks, chunk_spp, n_items;
+  uint32_t trace_spb;                  // segments per k_trace workgroup pass: its per-BSDF lists span that many segments
   int stack_depth;                     // LDS traversal stack entries per lane
 };
 

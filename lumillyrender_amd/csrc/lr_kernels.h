@@ -794,16 +794,17 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 //     fewer than kRefillBelow lanes of the wave are still walking.  Ray depths differ by 10x in one
 //     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use.
 //   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
-constexpr int kMaxGroup = 8;             // segments a workgroup may own at once
+constexpr int kMaxGroup = 32;            // segments a workgroup may own at once (16 K rays per pass: long passes amortise the run-down of the last rays)
 #ifndef LR_REFILL_BELOW
 #define LR_REFILL_BELOW 44
 #endif
+static_assert(kMaxGroup * 8 == kBlock, "k_shadow loads one sub-list count per thread");
 constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
 
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint32_t s_cnt[kMaxGroup * 8];
+  __shared__ uint32_t s_cnt[8];                                    // one list per BSDF for the whole range of this pass (k_shade cuts it into 512-entry slices)
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
@@ -813,7 +814,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
   for (uint32_t seg0 = blockIdx.x * spb; seg0 < st.n_seg; seg0 += gridDim.x * spb) {
     const uint32_t nsegs = st.n_seg - seg0 < spb ? st.n_seg - seg0 : spb;
     const uint32_t total = nsegs * kSeg, slot0 = seg0 * kSeg;
-    if (tid < kMaxGroup * 8) s_cnt[tid] = 0;
+    if (tid < 8) s_cnt[tid] = 0;
     if (tid == 0) s_next = 0;
     __syncthreads();
     if (sc.n_flat > 0) {
@@ -830,14 +831,13 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
           n_rays += 1;
           if (COUNT) n_tst += r.tests;
         }
-        uint32_t sg = base / kSeg;                                  // wave-uniform
         uint64_t todo = __ballot(active);
         while (todo) {
           int lead = (int)__builtin_ctzll(todo);
           int q = __shfl(qid, lead, 64);
           bool mine = active && qid == q;
-          uint32_t idx = wave_reserve(&s_cnt[sg * 8 + q], mine);
-          if (mine) st.q_shade[((size_t)q * st.n_seg + seg0 + sg) * kSeg + idx] = slot;
+          uint32_t idx = wave_reserve(&s_cnt[q], mine);
+          if (mine) st.q_shade[((size_t)q * st.n_seg + seg0) * kSeg + idx] = slot;
           todo &= ~__ballot(mine);
         }
       }
@@ -852,8 +852,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
           int key = -1;
           if (f) {
             st.hit[slot] = make_float2(tr.t, __int_as_float(tr.prim));
-            int qid = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
-            key = (int)((slot - slot0) / kSeg) * 8 + qid;
+            key = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
             if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
           }
           uint64_t todo = __ballot(f);
@@ -862,7 +861,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
             int k = __shfl(key, lead, 64);
             bool mine = f && key == k;
             uint32_t idx = wave_reserve(&s_cnt[k], mine);
-            if (mine) st.q_shade[((size_t)(k & 7) * st.n_seg + seg0 + (uint32_t)(k >> 3)) * kSeg + idx] = slot;
+            if (mine) st.q_shade[((size_t)k * st.n_seg + seg0) * kSeg + idx] = slot;
             todo &= ~__ballot(mine);
           }
           if (f) { has = false; fin = false; }
@@ -889,7 +888,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, cons
       }
     }
     __syncthreads();
-    if (tid < nsegs * 8 && (tid & 7) < kNumShadeQueues) st.c_shade[(tid & 7) * st.n_seg + seg0 + (tid >> 3)] = s_cnt[tid];
+    if (tid < kNumShadeQueues) st.c_shade[tid * st.n_seg + seg0] = s_cnt[tid];      // the range's lists start in its first segment's storage
     __syncthreads();
   }
   stat_accumulate(&s_stat[ST_SEGMENTS], n_rays);
@@ -1002,8 +1001,12 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
   for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-    const uint32_t n = st.c_shade[MT * st.n_seg + seg];
-    const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + seg) * kSeg;
+    // k_trace left ONE list per BSDF for each range of trace_spb segments (contiguous storage); this workgroup
+    // shades the seg-th 512-entry slice of it
+    const uint32_t g0 = seg / st.trace_spb * st.trace_spb, lo = (seg - g0) * kSeg;
+    const uint32_t n_range = st.c_shade[MT * st.n_seg + g0];
+    const uint32_t n = n_range > lo ? (n_range - lo < (uint32_t)kSeg ? n_range - lo : (uint32_t)kSeg) : 0u;
+    const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + g0) * kSeg + lo;
     uint32_t* shadow_q = st.q_shadow + ((size_t)(MT == kQMiss ? 0 : MT) * st.n_seg + seg) * kSeg;
     if (threadIdx.x == 0) { pool_begin(st, seg, n, &pl, false); s_shadow = 0; s_retired = 0; }
     __syncthreads();
@@ -1052,15 +1055,21 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
   for (uint32_t seg0 = blockIdx.x * spb; seg0 < st.n_seg; seg0 += gridDim.x * spb) {
     const uint32_t nsegs = st.n_seg - seg0 < spb ? st.n_seg - seg0 : spb;
     __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (uint32_t sg = 0; sg < nsegs; ++sg)
-        for (int k = 0; k < 8; ++k) {
-          s_pref[sg * 8 + k] = acc;
-          if (k < kNumShadeQueues - 1 && (mt_mask & (1u << k))) acc += st.c_shadow[k * st.n_seg + seg0 + sg];
-        }
-      s_pref[nsegs * 8] = acc;
-      s_next = 0;
+    {
+      const uint32_t sg = tid >> 3, k = tid & 7u;                   // kMaxGroup * 8 == kBlock: one sub-list per thread
+      uint32_t c = 0;
+      if (sg < nsegs && k < (uint32_t)kNumShadeQueues - 1 && (mt_mask & (1u << k))) c = st.c_shadow[k * st.n_seg + seg0 + sg];
+      s_pref[tid + 1] = c;
+    }
+    __syncthreads();
+    if (tid < 64) {                                                 // prefix over the 256 counts: 4 per lane + a wave scan
+      uint32_t v0 = s_pref[4 * tid + 1], v1 = s_pref[4 * tid + 2], v2 = s_pref[4 * tid + 3], v3 = s_pref[4 * tid + 4];
+      uint32_t tot = v0 + v1 + v2 + v3, inc = tot;
+      for (int off = 1; off < 64; off <<= 1) { uint32_t up = __shfl_up(inc, off, 64); if ((int)tid >= off) inc += up; }
+      uint32_t base = inc - tot;
+      s_pref[4 * tid + 1] = base + v0; s_pref[4 * tid + 2] = base + v0 + v1;
+      s_pref[4 * tid + 3] = base + v0 + v1 + v2; s_pref[4 * tid + 4] = base + tot;
+      if (tid == 0) { s_pref[0] = 0; s_next = 0; }
     }
     __syncthreads();
     const uint32_t total = s_pref[nsegs * 8], nsub = nsegs * 8;

@@ -420,7 +420,11 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
   const int resident_per_cu = std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
-  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : (1u << 20));
+  // streaming: enough slots that a k_trace workgroup pass covers many rays per lane (the run-down of a pass's last
+  // rays is what idles lanes: 1 M slots = 4 rays per lane left 23 % of the lanes busy in a node step), but no more
+  // than 1/8 of the work items so that the render as a whole still has many iterations; 136 B of state per slot
+  const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(16u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
+  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : stream_slots);
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
@@ -481,6 +485,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
   const uint32_t spb_trace = std::min<uint32_t>(kMaxGroup, (n_seg + g_trace - 1) / g_trace);     // segments per workgroup pass
   const uint32_t spb_shadow = std::min<uint32_t>(kMaxGroup, (n_seg + g_shadow - 1) / g_shadow);
+  ds.trace_spb = spb_trace;
   const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_seg * kBlock);
   int g_shade[kNumShadeQueues];
   g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_seg * kBlock);
