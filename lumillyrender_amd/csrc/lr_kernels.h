@@ -216,7 +216,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
 // together, then the lanes that reached a leaf run their primitive tests together).  Clears `go` of lanes
 // whose ray is finished.
 #ifndef LR_DESCEND_BURST
-#define LR_DESCEND_BURST 4
+#define LR_DESCEND_BURST 3
 #endif
 constexpr int kDescendBurst = LR_DESCEND_BURST;
 template <bool SHADOW>
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 //   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
 constexpr int kMaxGroup = 32;            // segments a workgroup may own at once (16 K rays per pass: long passes amortise the run-down of the last rays)
 #ifndef LR_REFILL_BELOW
-#define LR_REFILL_BELOW 44
+#define LR_REFILL_BELOW 32
 #endif
 static_assert(kMaxGroup * 8 == kBlock, "k_shadow loads one sub-list count per thread");
 constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
