@@ -696,14 +696,14 @@ LR_DEV void start_sample(const DevScene& sc, const DevState& st, const DevParams
 // pass), lanes then draw from it with LDS atomics only.
 struct PoolLds { uint32_t r0, a0, r1, a1, taken; };
 
-LR_DEV void pool_begin(const DevState& st, uint32_t seg, uint32_t need_max, PoolLds* pl, bool reset) {
+LR_DEV void pool_begin(const DevState& st, uint32_t seg, uint32_t need_max, PoolLds* pl, bool reset, uint32_t batch = kSeg) {
   uint4 p = reset ? make_uint4(0, 0, 0, 0) : st.pool[seg];       // {r0 next, r0 end, r1 next, r1 end}
   if (p.x >= p.y) { p.x = p.z; p.y = p.w; p.z = p.w = 0; }
   if (p.y - p.x < need_max && p.z >= p.w) {
     uint32_t cur = __hip_atomic_load(st.next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur < st.n_items) {
-      uint32_t nb = atomicAdd(st.next_item, (uint32_t)kSeg);
-      if (nb < st.n_items) { p.z = nb; p.w = nb + kSeg < st.n_items ? nb + kSeg : st.n_items; }
+      uint32_t nb = atomicAdd(st.next_item, batch);
+      if (nb < st.n_items) { p.z = nb; p.w = st.n_items - nb > batch ? nb + batch : st.n_items; }
     }
     if (p.x >= p.y) { p.x = p.z; p.y = p.w; p.z = p.w = 0; }
   }
@@ -1000,15 +1000,20 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   __shared__ uint32_t s_stat[ST_COUNT];
   if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
-  for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-    // k_trace left ONE list per BSDF for each range of trace_spb segments (contiguous storage); this workgroup
-    // shades the seg-th 512-entry slice of it
-    const uint32_t g0 = seg / st.trace_spb * st.trace_spb, lo = (seg - g0) * kSeg;
-    const uint32_t n_range = st.c_shade[MT * st.n_seg + g0];
-    const uint32_t n = n_range > lo ? (n_range - lo < (uint32_t)kSeg ? n_range - lo : (uint32_t)kSeg) : 0u;
-    const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + g0) * kSeg + lo;
-    uint32_t* shadow_q = st.q_shadow + ((size_t)(MT == kQMiss ? 0 : MT) * st.n_seg + seg) * kSeg;
-    if (threadIdx.x == 0) { pool_begin(st, seg, n, &pl, false); s_shadow = 0; s_retired = 0; }
+  // k_trace left ONE list per BSDF for each range of trace_spb segments (contiguous storage).  A workgroup shades a
+  // whole range: the range's slots then all draw their work items from ONE pool (the range's first segment's) that
+  // this workgroup owns, so a pool can only run dry, never be stranded with items nobody asks for.
+  const uint32_t n_ranges = (st.n_seg + st.trace_spb - 1) / st.trace_spb;
+  for (uint32_t g = blockIdx.x; g < n_ranges; g += gridDim.x) {
+    const uint32_t g0 = g * st.trace_spb;
+    const uint32_t nsegs = st.n_seg - g0 < st.trace_spb ? st.n_seg - g0 : st.trace_spb;
+    const uint32_t n = st.c_shade[MT * st.n_seg + g0];
+    const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + g0) * kSeg;
+    uint32_t* shadow_q = st.q_shadow + ((size_t)(MT == kQMiss ? 0 : MT) * st.n_seg + g0) * kSeg;   // same contiguous layout: one list per range
+    // reservations of a quarter of the list (512..8192 items): draws are a fraction of the finishing lanes; a pool
+    // that still runs short falls back to the global dispenser (finish_and_regenerate), it never loses work
+    const uint32_t batch = n / 4 < (uint32_t)kSeg ? (uint32_t)kSeg : (n / 4 > 8192u ? 8192u : n / 4);
+    if (threadIdx.x == 0) { pool_begin(st, g0, n < batch ? n : batch, &pl, false, batch); s_shadow = 0; s_retired = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < n; base += kBlock) {
       uint32_t i = base + threadIdx.x;
@@ -1026,9 +1031,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
       }
     }
     __syncthreads();
+    if (MT != kQMiss && threadIdx.x < nsegs) st.c_shadow[MT * st.n_seg + g0 + threadIdx.x] = threadIdx.x == 0 ? s_shadow : 0u;
     if (threadIdx.x == 0) {
-      pool_end(st, seg, &pl);
-      if (MT != kQMiss) st.c_shadow[MT * st.n_seg + seg] = s_shadow;
+      pool_end(st, g0, &pl);
       if (s_retired) atomicAdd(st.n_retired, s_retired);
     }
     __syncthreads();

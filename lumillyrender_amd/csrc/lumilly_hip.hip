@@ -484,16 +484,17 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const int g_trace = grid_for(ktrace, s.n_cus, lds, n_seg * kBlock);
   const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
   const uint32_t spb_trace = std::min<uint32_t>(kMaxGroup, (n_seg + g_trace - 1) / g_trace);     // segments per workgroup pass
-  const uint32_t spb_shadow = std::min<uint32_t>(kMaxGroup, (n_seg + g_shadow - 1) / g_shadow);
+  const uint32_t spb_shadow = spb_trace;      // k_shade leaves one shadow list per trace range: k_shadow must walk whole ranges
   ds.trace_spb = spb_trace;
   const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_seg * kBlock);
   int g_shade[kNumShadeQueues];
-  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_seg * kBlock);
-  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_seg * kBlock);
-  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_seg * kBlock);
-  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_seg * kBlock);
-  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_seg * kBlock);
-  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_seg * kBlock);
+  const uint32_t n_ranges = (n_seg + spb_trace - 1) / spb_trace;   // k_shade: one workgroup per trace range
+  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_ranges * kBlock);
+  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_ranges * kBlock);
+  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_ranges * kBlock);
+  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_ranges * kBlock);
+  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_ranges * kBlock);
+  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_ranges * kBlock);
 
   DevScene dsc = s.dev;
   dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
