@@ -146,6 +146,8 @@ def main():
             acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]; acc["kernel_launches"][k] += st.kernel_launches[k]
     barrier()
     elapsed = time.perf_counter() - t0
+    my_pixels = sum(tiles[i].w * tiles[i].h for i in range(n_tiles))
+    assert acc["samples"] == my_pixels * spp * args.steps, f"device finished {acc['samples']} samples, expected {my_pixels * spp * args.steps}"
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=host_group)
