@@ -798,7 +798,6 @@ constexpr int kMaxGroup = 32;            // segments a workgroup may own at once
 #ifndef LR_REFILL_BELOW
 #define LR_REFILL_BELOW 32
 #endif
-static_assert(kMaxGroup * 8 == kBlock, "k_shadow loads one sub-list count per thread");
 constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
 
 template <bool COUNT>
@@ -1006,7 +1005,6 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   const uint32_t n_ranges = (st.n_seg + st.trace_spb - 1) / st.trace_spb;
   for (uint32_t g = blockIdx.x; g < n_ranges; g += gridDim.x) {
     const uint32_t g0 = g * st.trace_spb;
-    const uint32_t nsegs = st.n_seg - g0 < st.trace_spb ? st.n_seg - g0 : st.trace_spb;
     const uint32_t n = st.c_shade[MT * st.n_seg + g0];
     const uint32_t* queue = st.q_shade + ((size_t)MT * st.n_seg + g0) * kSeg;
     uint32_t* shadow_q = st.q_shadow + ((size_t)(MT == kQMiss ? 0 : MT) * st.n_seg + g0) * kSeg;   // same contiguous layout: one list per range
@@ -1031,7 +1029,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
       }
     }
     __syncthreads();
-    if (MT != kQMiss && threadIdx.x < nsegs) st.c_shadow[MT * st.n_seg + g0 + threadIdx.x] = threadIdx.x == 0 ? s_shadow : 0u;
+    if (MT != kQMiss && threadIdx.x == 0) st.c_shadow[MT * st.n_seg + g0] = s_shadow;
     if (threadIdx.x == 0) {
       pool_end(st, g0, &pl);
       if (s_retired) atomicAdd(st.n_retired, s_retired);
@@ -1046,11 +1044,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 
 // Shadow stage of the streaming pipeline (scene.rs:127-147).  mt_mask = BSDF types present in the scene
 // (their k_shade wrote this iteration's shadow lists).  Same workgroup ranges and the same dynamic ray
-// fetch as k_trace; the work list is the concatenation of the (segment, BSDF) shadow lists of the range.
+// fetch as k_trace; the work list is the concatenation of the range's per-BSDF shadow lists.
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
-  __shared__ uint32_t s_pref[kMaxGroup * 8 + 1];                   // prefix over (segment, BSDF) sub-lists
+  __shared__ uint32_t s_pref[8];                                    // prefix over the range's per-BSDF shadow lists (k_shade writes one per range)
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
@@ -1058,30 +1056,23 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uin
   if (tid < ST_COUNT) s_stat[tid] = 0;
   uint32_t n_q = 0, n_vis = 0, n_tst = 0;
   for (uint32_t seg0 = blockIdx.x * spb; seg0 < st.n_seg; seg0 += gridDim.x * spb) {
-    const uint32_t nsegs = st.n_seg - seg0 < spb ? st.n_seg - seg0 : spb;
     __syncthreads();
-    {
-      const uint32_t sg = tid >> 3, k = tid & 7u;                   // kMaxGroup * 8 == kBlock: one sub-list per thread
-      uint32_t c = 0;
-      if (sg < nsegs && k < (uint32_t)kNumShadeQueues - 1 && (mt_mask & (1u << k))) c = st.c_shadow[k * st.n_seg + seg0 + sg];
-      s_pref[tid + 1] = c;
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int k = 0; k < kNumShadeQueues - 1; ++k) {
+        s_pref[k] = acc;
+        if (mt_mask & (1u << k)) acc += st.c_shadow[k * st.n_seg + seg0];
+      }
+      s_pref[kNumShadeQueues - 1] = acc;
+      s_next = 0;
     }
     __syncthreads();
-    if (tid < 64) {                                                 // prefix over the 256 counts: 4 per lane + a wave scan
-      uint32_t v0 = s_pref[4 * tid + 1], v1 = s_pref[4 * tid + 2], v2 = s_pref[4 * tid + 3], v3 = s_pref[4 * tid + 4];
-      uint32_t tot = v0 + v1 + v2 + v3, inc = tot;
-      for (int off = 1; off < 64; off <<= 1) { uint32_t up = __shfl_up(inc, off, 64); if ((int)tid >= off) inc += up; }
-      uint32_t base = inc - tot;
-      s_pref[4 * tid + 1] = base + v0; s_pref[4 * tid + 2] = base + v0 + v1;
-      s_pref[4 * tid + 3] = base + v0 + v1 + v2; s_pref[4 * tid + 4] = base + tot;
-      if (tid == 0) { s_pref[0] = 0; s_next = 0; }
-    }
-    __syncthreads();
-    const uint32_t total = s_pref[nsegs * 8], nsub = nsegs * 8;
+    const uint32_t total = s_pref[kNumShadeQueues - 1];
+    const uint32_t p1 = s_pref[1], p2 = s_pref[2], p3 = s_pref[3], p4 = s_pref[4];
     auto entry_slot = [&](uint32_t i) -> uint32_t {                 // i-th shadow ray of the range -> slot id
-      uint32_t lo = 0, hi = nsub - 1;
-      while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= i) lo = mid; else hi = mid - 1; }
-      return st.q_shadow[((size_t)(lo & 7) * st.n_seg + seg0 + (lo >> 3)) * kSeg + (i - s_pref[lo])];
+      uint32_t k = (i >= p1 ? 1u : 0u) + (i >= p2 ? 1u : 0u) + (i >= p3 ? 1u : 0u) + (i >= p4 ? 1u : 0u);
+      uint32_t base = k == 0 ? 0u : (k == 1 ? p1 : (k == 2 ? p2 : (k == 3 ? p3 : p4)));
+      return st.q_shadow[((size_t)k * st.n_seg + seg0) * kSeg + (i - base)];
     };
     if (sc.n_flat > 0) {
       for (uint32_t i = tid; i < total; i += kBlock) {
