@@ -722,12 +722,13 @@ LR_DEV void pool_end(const DevState& st, uint32_t seg, const PoolLds* pl) {
 //   fresh    : this lane has no work item yet (k_generate)
 // Returns true when the lane found the pool (and the dispenser) empty and retired its slot.
 LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const DevParams& rp, PoolLds* pl, uint32_t slot,
-                                  bool finished, bool fresh, V3 L, float g_term, uint32_t pixel, uint32_t sample) {
+                                  bool finished, bool fresh, V3 L, float g_term, uint32_t pixel, uint32_t sample,
+                                  const float4* acc_early = nullptr) {   // acc_early: the slot's chunk-sum row, loaded by the caller ahead of the shading (one round trip less)
   bool need_item = fresh;
   uint32_t item = 0;
   V3 sum = v3(0, 0, 0);
   if (finished) {
-    float4 a = st.acc[slot];
+    float4 a = acc_early ? *acc_early : st.acc[slot];
     item = __float_as_uint(a.w);
     V3 delta = L;
     if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (L * g_term) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
@@ -1018,10 +1019,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
       bool valid = i < n;
       uint32_t slot = valid ? queue[i] : 0;
       VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
+      float4 acc_row = st.acc[slot];                                // every wave finishes some path: fetch the chunk sum with the rest of the state
       if (valid) v = shade_vertex<MT>(sc, st, rp, slot);
       if (v.finished) n_done += 1;
       if (v.sky_fetch) n_sky += 1;
-      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample);
+      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample, &acc_row);
       (void)wave_reserve(&s_retired, r);
       if (MT != kQMiss) {
         uint32_t idx = wave_reserve(&s_shadow, v.has_shadow);
