@@ -1,4 +1,4 @@
-"""Random small scenes, device film vs oracle film.  usage: fuzz_parity.py first_seed n_seeds [W H spp]
+"""Random small scenes, device film vs oracle film.  usage: fuzz_parity.py first_seed n_seeds [W H spp [max_objects]]
 A scene: 3..60 primitives (spheres and transformed quads, so both the flat loop and the 4-wide tree are used), all five
 BSDFs with random parameters, one or two area lights or a bright sky, pinhole / thin-lens / omnidirectional camera,
 pt or pt-direct.  Reports the worst |device - oracle| relative to max(1, |oracle|) per scene."""
@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, ".")
 
 
-def scene_text(seed, W, H):
+def scene_text(seed, W, H, max_objs=26):
     r = np.random.default_rng(seed)
     u = lambda a, b: float(r.uniform(a, b))
     v3 = lambda a, b: "[%.6g, %.6g, %.6g]" % (u(a, b), u(a, b), u(a, b))
@@ -25,7 +25,7 @@ def scene_text(seed, W, H):
         else:
             mats.append(f'[[material]]\nname = "{name}"\ntype = "ideal-refraction"\nreflectance = {v3(0.6, 1.0)}\nior = {u(1.1, 2.0):.6g}\nabsorbtance = {u(0, 0.02):.6g}')
         names.append(name)
-    n_prim_objs = int(r.integers(2, 26))
+    n_prim_objs = int(r.integers(2, max_objs))
     objs = []
     size = 100.0
     for i in range(n_prim_objs):
@@ -74,10 +74,10 @@ color = {sky}
     return text, integ, cam_kind
 
 
-def run(seed, W, H, spp):
+def run(seed, W, H, spp, max_objs=26):
     from lumillyrender_amd import host, device
     from oracle import binding as oracle
-    text, integ, cam = scene_text(seed, W, H)
+    text, integ, cam = scene_text(seed, W, H, max_objs)
     desc = host.Description(text=text)
     desc.set_resolution(W, H)
     params = desc.render_params(spp=spp, seed=seed)
@@ -100,10 +100,11 @@ def run(seed, W, H, spp):
 if __name__ == "__main__":
     first, n = int(sys.argv[1]), int(sys.argv[2])
     W, H, spp = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (48, 32, 8)
+    max_objs = int(sys.argv[6]) if len(sys.argv) > 6 else 26
     bad = 0
     for seed in range(first, first + n):
         try:
-            worst, n_prims, integ, cam, mean, lit = run(seed, W, H, spp)
+            worst, n_prims, integ, cam, mean, lit = run(seed, W, H, spp, max_objs)
         except Exception as e:                             # a scene the loader rejects is a generator problem, report and go on
             print(f"seed {seed}: ERROR {e}")
             bad += 1
