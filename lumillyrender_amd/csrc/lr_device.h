@@ -30,7 +30,7 @@
 namespace lr {
 
 constexpr int kBlock = 256;            // 4 waves of 64
-constexpr int kStackLdsMax = 31;       // traversal stack entries per lane kept in LDS by the streaming kernels
+constexpr int kStackLdsMax = 25;       // traversal stack entries per lane kept in LDS by the streaming kernels (6 workgroups of 25 KB per CU)
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
 constexpr int kFlatMax = 32;          // scenes up to this many primitives skip the tree

@@ -795,6 +795,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 //     fewer than kRefillBelow lanes of the wave are still walking.  Ray depths differ by 10x in one
 //     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use.
 //   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
+#ifndef LR_TRACE_WAVES
+#define LR_TRACE_WAVES 6
+#endif
 constexpr int kMaxGroup = 32;            // segments a workgroup may own at once (16 K rays per pass: long passes amortise the run-down of the last rays)
 #ifndef LR_REFILL_BELOW
 #define LR_REFILL_BELOW 32
@@ -802,7 +805,7 @@ constexpr int kMaxGroup = 32;            // segments a workgroup may own at once
 constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
+__global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_cnt[8];                                    // one list per BSDF for the whole range of this pass (k_shade cuts it into 512-entry slices)
   __shared__ uint32_t s_next;
@@ -1048,7 +1051,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 // (their k_shade wrote this iteration's shadow lists).  Same workgroup ranges and the same dynamic ray
 // fetch as k_trace; the work list is the concatenation of the range's per-BSDF shadow lists.
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
+__global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_pref[8];                                    // prefix over the range's per-BSDF shadow lists (k_shade writes one per range)
   __shared__ uint32_t s_next;

@@ -470,8 +470,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
-  // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (5 workgroups of 31 KB per CU, the
-  // VGPR-limited occupancy), the rest of the worst case in a spill buffer that near-first traversal rarely reaches
+  // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (6 workgroups of 25 KB per CU, the
+  // occupancy their 80 VGPRs allow), the rest of the worst case in a spill buffer that near-first traversal rarely reaches
   const int stack_in_lds = resident ? s.stack_depth : std::min(s.stack_depth, stack_lds_limit());
   const size_t lds = (size_t)stack_in_lds * kBlock * 4;
   const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
