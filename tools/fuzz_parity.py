@@ -84,7 +84,7 @@ def run(seed, W, H, spp, max_objs=26):
     want = oracle.render(desc, params, threads=0)
     scene = device.Scene(desc)
     worst = 0.0
-    for flags in (0, 4):                                   # default pipeline, then streaming
+    for flags in (0, 4, 8):                                # default pipeline, forced streaming, forced resident (falls back to the default choice when it does not fit)
         params.flags = flags
         got = scene.render(params)
         assert scene.stats().samples == W * H * spp
