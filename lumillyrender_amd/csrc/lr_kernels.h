@@ -1191,6 +1191,11 @@ static_assert(kRSeg <= 256, "slot numbers are stored in bytes");
 #ifndef LR_RES_WAVES
 #define LR_RES_WAVES 6
 #endif
+// FLAT: the scene is tested without a tree (n_flat > 0); the instantiation carries no traversal code, so its
+// register allocation is not burdened by the 4-wide node step it never runs.
+// MTS: the BSDF bodies compiled in (bit k = LR_MAT_* k); the Lambert-only instantiation (the headline scene class)
+// allocates registers for one shading body instead of the most demanding of five.
+template <bool FLAT, uint32_t MTS>
 __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
   extern __shared__ float4 lds4[];
   __shared__ PoolLds pl;
@@ -1243,9 +1248,11 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
       if (__float_as_int(ro.w) >= 0) {
         float4 rd = st.ray_d[slot];
         active = true;
-        TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f) : traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, nullptr);
+        TraceResult r;
+        if (FLAT) r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
+        else r = traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, nullptr);
         st.sh_w[slot] = make_float4(r.t, __int_as_float(r.prim), 0.0f, 0.0f);
-        qid = r.prim < 0 ? kQMiss : (sc.n_flat > 0 ? (int)s_qid[r.prim] : (int)sc.prim_qid[r.prim]);
+        qid = r.prim < 0 ? kQMiss : (FLAT ? (int)s_qid[r.prim] : (int)sc.prim_qid[r.prim]);
         n_seg += 1;
       }
       // a ray that left the scene is finished (sky lookup, fold, next camera sample): right here when at least
@@ -1284,11 +1291,11 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
     if (tid == kBlock - 1) pool_step(st, &pl, kPoolLow, kPoolBatch);   // keeps a few iterations of draws; small batches keep the end-of-render tail short
     uint32_t next_chunk = 0;
-    if (mt_mask & 1u) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if (mt_mask & 2u) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if (mt_mask & 4u) resident_shade_list<2>(sc, st, rp, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if (mt_mask & 8u) resident_shade_list<3>(sc, st, rp, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if (mt_mask & 16u) resident_shade_list<4>(sc, st, rp, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 4u) && (mt_mask & 4u)) resident_shade_list<2>(sc, st, rp, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 8u) && (mt_mask & 8u)) resident_shade_list<3>(sc, st, rp, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 16u) && (mt_mask & 16u)) resident_shade_list<4>(sc, st, rp, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     LR_TICK(3)
     __syncthreads();
     LR_TICK(0)
@@ -1307,7 +1314,9 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
           float4 ro = st.ray_o[slot];
           float4 sd = st.sh_d[slot];
           V3 o = v3(ro), dir = v3(sd);
-          TraceResult r = sc.n_flat > 0 ? traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w) : traverse<true>(sc, o, dir, sd.w, stk_n, nullptr);
+          TraceResult r;
+          if (FLAT) r = traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w);
+          else r = traverse<true>(sc, o, dir, sd.w, stk_n, nullptr);
           n_shq += 1;
           shadow_resolve(sc, st, slot, o, dir, r);
         }

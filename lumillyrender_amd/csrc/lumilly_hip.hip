@@ -507,8 +507,13 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
-    HIP_OK(hipFuncSetAttribute((const void*)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-    L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(k_resident, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
+    auto launch_resident = [&](auto kernel) {
+      HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
+      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
+    };
+    if (s.dev.n_flat > 0 && mt_mask == 1u) launch_resident(k_resident<true, 1u>);        // flat, Lambert only
+    else if (s.dev.n_flat > 0) launch_resident(k_resident<true, 31u>);
+    else launch_resident(k_resident<false, 31u>);
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {
