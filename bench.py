@@ -92,6 +92,7 @@ def main():
 
     dist = None
     host_group = None
+    dev_group = None
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the env switch exercises the RCCL path on a 1-GPU box
     if use_dist:
         import torch.distributed as dist_mod
@@ -100,12 +101,22 @@ def main():
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        # host side (film gather, max of the timings): gloo, the default group.  Device side (the barrier that
+        # brackets the timed region): an RCCL group when it comes up; a machine where it does not still gets its
+        # numbers through the gloo barrier + device synchronisation.
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        host_group = None
         if "nccl" in args.backend:
-            dist.init_process_group(backend=args.backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            host_group = dist.new_group(backend="gloo")            # the film gather runs on the host
-        else:
-            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-            host_group = None
+            try:
+                import datetime
+                dev_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe, group=dev_group)
+                torch.cuda.synchronize(local_rank)
+                assert int(probe.item()) == world
+            except Exception as e:                                     # noqa: BLE001 -- report and fall back
+                print(f"[bench] rank {rank}: RCCL group unavailable ({type(e).__name__}: {e}); using the gloo barrier", file=sys.stderr, flush=True)
+                dev_group = None
     dev_index = local_rank if world > 1 else 0
 
     W, H = args.width, args.height
@@ -116,13 +127,15 @@ def main():
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
     flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
     canvas = np.zeros((H, W, 3), dtype=np.float32)
-    barrier_buf = None
-    if use_dist:
-        barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if "nccl" in args.backend else torch.zeros(1)
+    barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if (use_dist and dev_group is not None) else None
 
     def barrier():
+        torch.cuda.synchronize(dev_index)
         if dist is not None:
-            dist.all_reduce(barrier_buf)
+            if dev_group is not None:
+                dist.all_reduce(barrier_buf, group=dev_group)           # RCCL over xGMI
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev_index)
 
     def step(i):
@@ -150,7 +163,7 @@ def main():
     assert acc["samples"] == my_pixels * spp * args.steps, f"device finished {acc['samples']} samples, expected {my_pixels * spp * args.steps}"
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=host_group)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     total_samples = float(W) * H * spp * args.steps
