@@ -228,6 +228,8 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 0), "bytes_per_camera_sample": round(bytes_per_sample, 1),
                 "boxes_per_query": round(v_per_q, 2), "prim_tests_per_query": round(t_per_q, 2),
                 "timed_launches": acc["kernel_timed"][dom],
+                # the MEASURED HBM rate next to the algorithmic one (PMC bytes of profiles/traffic.json over this run's launch time)
+                "measured_hbm_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None,
             }
             out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
                                             for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
