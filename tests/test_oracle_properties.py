@@ -201,3 +201,25 @@ def test_oracle_matches_committed_golden(case):
     img, _, _ = _render(name, w, h, spp, integrator=integ, seed=seed)
     ref = np.load(os.path.join(GOLDEN, golden_name(case)))
     assert np.array_equal(img, ref)
+
+
+def test_fuzz_generator_scenes_load_and_render():
+    """tools/fuzz_parity.py's random scenes (used by the GPU suite) must stay loadable: three seeds through the host
+    loader and the oracle, finite film, both integrators and several cameras among them."""
+    import importlib.util, os
+    import numpy as np
+    from lumillyrender_amd import host
+    from oracle import binding as oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    seen = set()
+    for seed in (0, 1, 5, 17):
+        text, integ, cam = fz.scene_text(seed, 16, 12)
+        desc = host.Description(text=text)
+        desc.set_resolution(16, 12)
+        img = oracle.render(desc, desc.render_params(spp=2, seed=seed), threads=1)
+        assert img.shape == (12, 16, 3) and np.isfinite(img).all()
+        seen.add((integ, cam))
+    assert len(seen) >= 3
