@@ -126,7 +126,8 @@ def main():
     scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
     flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
-    canvas = np.zeros((H, W, 3), dtype=np.float32)
+    shared_film = multigpu.SharedFilm(W, H, args.tile, dist, dst=0, group=host_group)   # one film in /dev/shm for the ranks of this node
+    canvas = shared_film.array
     barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if (use_dist and dev_group is not None) else None
 
     def barrier():
@@ -142,7 +143,7 @@ def main():
         params = desc.render_params(spp=spp, seed=i, integrator=abi.LR_INTEGRATOR_PT_DIRECT, flags=flags, path_slots=args.slots)
         scene.render(params, tiles, n_tiles, out=canvas)      # blocks until the film tiles are on the host
         st = scene.stats()
-        multigpu.gather_tiles(canvas, W, H, args.tile, dist, dst=0, group=host_group)   # host gather of each rank's packed tiles (gloo)
+        shared_film.collect()                                   # every rank's tiles are in the shared film; a barrier publishes it to rank 0
         return st
 
     for i in range(args.warmup):
@@ -180,7 +181,7 @@ def main():
                 "workload": f"{args.scene} (the reference's scenes/new-cbox.toml with authored Cornell meshes) "
                             f"{W}x{H} {spp} spp pt-direct, Lambert only",
                 "width": W, "height": H, "spp": spp, "integrator": "pt-direct", "tile": args.tile,
-                "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, host gather",
+                "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, film assembled in host shared memory",
                 "path_slots": args.slots or "library default",
             },
         }
@@ -239,6 +240,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, args)
         print(json.dumps(out), flush=True)
     scene.close()
+    shared_film.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

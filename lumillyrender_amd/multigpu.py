@@ -2,11 +2,15 @@
 
 The path shards without any exchange step (pixels are independent jobs in the reference,
 main.rs:73-126): every rank holds the whole scene, renders the tiles `i % world == rank` of the
-row-major tile grid into a zeroed film, and rank 0 collects every rank's tile pixels over the host
-(gloo gather of the packed tiles, 1/world of the film per rank) -- the counterpart of the reference's
-channel drain (main.rs:129-132).  No RCCL collective is on the data path.  RNG keys are (seed, pixel, sample), so the assembled film is bit-identical to a
+row-major tile grid, and the film is assembled on the host -- the counterpart of the reference's channel drain
+(main.rs:129-132): on one node every rank's lr_render writes its tiles straight into ONE film in POSIX shared
+memory (SharedFilm; lr_render only touches the pixels of the tiles it is given) and a barrier publishes it; across
+nodes rank 0 gathers each rank's packed tiles over gloo (gather_tiles).  No RCCL collective is on the data path.  RNG keys are (seed, pixel, sample), so the assembled film is bit-identical to a
 single-rank render.
 """
+import os
+import time
+
 import numpy as np
 
 from . import host
@@ -36,34 +40,103 @@ def gather_film(film, dist=None, dst=0, group=None):
     return film
 
 
-def _pack(film, tiles, n):
-    if n == 0:
-        return np.zeros(0, dtype=np.float32)
-    return np.concatenate([film[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w].reshape(-1) for t in (tiles[i] for i in range(n))])
+class _GatherPlan:
+    """Tile rectangles of every rank and reusable send / receive buffers for one (film size, tile, world, rank)."""
+
+    def __init__(self, width, height, tile, world, rank, is_dst):
+        import torch
+        self.rects = []                                            # per rank: [(y0, y1, x0, x1, offset_in_floats), ...]
+        sizes = []
+        for r in range(world):
+            tl, n = shard_tiles(width, height, tile, r, world)
+            off, rr = 0, []
+            for i in range(n):
+                t = tl[i]
+                rr.append((t.y0, t.y0 + t.h, t.x0, t.x0 + t.w, off))
+                off += t.w * t.h * 3
+            self.rects.append(rr)
+            sizes.append(off)
+        cap = max(max(sizes), 1)
+        self.send = np.zeros(cap, dtype=np.float32)
+        self.send_t = torch.from_numpy(self.send)                  # shares memory with self.send
+        self.recv = [np.zeros(cap, dtype=np.float32) for _ in range(world)] if is_dst else None
+        self.recv_t = [torch.from_numpy(a) for a in self.recv] if is_dst else None
+
+
+_plans = {}
 
 
 def gather_tiles(film, width, height, tile, dist=None, dst=0, group=None):
     """Collect the tile pixels every rank rendered into `film` on `dst`: each rank packs ITS tiles (1/world of the
-    film) and one gloo gather moves them, instead of reducing `world` whole films.  Returns the film on dst."""
+    film) and one gloo gather moves them, instead of reducing `world` whole films.  Buffers are allocated once per
+    film geometry and reused.  Returns the film on dst."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return film
-    import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    shards = [shard_tiles(width, height, tile, r, world) for r in range(world)]
-    sizes = [sum(tl[i].w * tl[i].h for i in range(n)) * 3 for tl, n in shards]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.float32)
-    mine = _pack(film, *shards[rank])
-    buf[:mine.size] = torch.from_numpy(mine)
-    recv = [torch.empty(cap, dtype=torch.float32) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, recv, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+    key = (width, height, tile, world, rank, dst)
+    plan = _plans.get(key)
+    if plan is None:
+        plan = _plans[key] = _GatherPlan(width, height, tile, world, rank, rank == dst)
+    for y0, y1, x0, x1, off in plan.rects[rank]:
+        plan.send[off:off + (y1 - y0) * (x1 - x0) * 3] = film[y0:y1, x0:x1].reshape(-1)
+    dist.gather(plan.send_t, plan.recv_t, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
     if rank == dst:
-        for r, (tl, n) in enumerate(shards):
+        for r in range(world):
             if r == rank:
                 continue
-            flat, off = recv[r].numpy(), 0
-            for i in range(n):
-                t = tl[i]
-                film[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] = flat[off:off + t.w * t.h * 3].reshape(t.h, t.w, 3)
-                off += t.w * t.h * 3
+            flat = plan.recv[r]
+            for y0, y1, x0, x1, off in plan.rects[r]:
+                film[y0:y1, x0:x1] = flat[off:off + (y1 - y0) * (x1 - x0) * 3].reshape(y1 - y0, x1 - x0, 3)
     return film
+
+
+class SharedFilm:
+    """The film all ranks of one node render into.  `array` is an (H, W, 3) float32 view of a file in /dev/shm mapped by
+    every rank; `collect()` makes the ranks' tiles visible on rank `dst` (a barrier).  Ranks on different hosts (or no
+    process group) get private arrays and `collect()` falls back to gather_tiles."""
+
+    def __init__(self, width, height, tile, dist=None, dst=0, group=None):
+        import socket
+        self.width, self.height, self.tile, self.dist, self.dst, self.group = width, height, tile, dist, dst, group
+        self.path = None
+        self.shared = False
+        active = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+        if active:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            hosts = [None] * world
+            dist.all_gather_object(hosts, socket.gethostname(), group=group)
+            self.shared = len(set(hosts)) == 1 and os.path.isdir("/dev/shm")
+        if self.shared:
+            box = [None]
+            if rank == dst:
+                self.path = f"/dev/shm/lumilly_film_{os.getpid()}_{time.time_ns()}.f32"
+                self.array = np.memmap(self.path, dtype=np.float32, mode="w+", shape=(height, width, 3))
+                box[0] = self.path
+            src = dist.get_global_rank(group, dst) if group is not None else dst
+            dist.broadcast_object_list(box, src=src, group=group)
+            if rank != dst:
+                self.path = box[0]
+                self.array = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+            self._owner = rank == dst
+            dist.barrier(group=group)
+        else:
+            self.array = np.zeros((height, width, 3), dtype=np.float32)
+            self._owner = False
+
+    def collect(self):
+        """After every rank rendered its tiles into `array`: the complete film is readable on dst."""
+        if self.shared:
+            self.dist.barrier(group=self.group)
+        else:
+            gather_tiles(self.array, self.width, self.height, self.tile, self.dist, dst=self.dst, group=self.group)
+        return self.array
+
+    def close(self):
+        if self.shared:
+            self.dist.barrier(group=self.group)
+            arr, self.array = self.array, None
+            del arr
+            if self._owner and self.path and os.path.exists(self.path):
+                os.unlink(self.path)
+            self.dist.barrier(group=self.group)                       # nobody returns before the file is gone
+            self.shared = False

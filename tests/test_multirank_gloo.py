@@ -59,3 +59,41 @@ def test_sharded_render_equals_single_rank(tmp_path, world, packed):
     ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4), threads=2)
     got = np.load(out_path)
     assert np.array_equal(got, ref)
+
+
+def _shared_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lumillyrender_amd import host, multigpu
+    from oracle import binding as oracle
+    desc = host.Description(scene_path("cbox-spheres.toml"))
+    desc.set_resolution(W, H)
+    params = desc.render_params(spp=SPP, seed=4)
+    film = multigpu.SharedFilm(W, H, TILE, dist, dst=0)
+    assert film.shared
+    tiles, n = multigpu.shard_tiles(W, H, TILE, rank, world)
+    img = oracle.render(desc, params, tiles, n, threads=1)
+    for i in range(n):                               # like lr_render: only the pixels of the tiles given
+        t = tiles[i]
+        film.array[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] = img[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w]
+    got = film.collect()
+    if rank == 0:
+        np.save(out_path, np.array(got))
+    path = film.path
+    film.close()
+    assert not os.path.exists(path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shared_memory_film(tmp_path, world):
+    """bench.py's single-node path: every rank writes its tiles into one film in /dev/shm."""
+    out_path = str(tmp_path / "film.npy")
+    mp.spawn(_shared_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    from lumillyrender_amd import host
+    from oracle import binding as oracle
+    desc = host.Description(scene_path("cbox-spheres.toml"))
+    desc.set_resolution(W, H)
+    ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4), threads=2)
+    assert np.array_equal(np.load(out_path), ref)
