@@ -93,6 +93,11 @@ struct DevState {
   uint32_t* rank_pixel;                // n_pix: film pixel of every pixel rank (k_rank_table), one load instead of a search per work item
   int n_tiles;
   uint32_t n_slots, n_seg, n_pix, n_chunks, chunk_spp, n_items;
+  // resident pipeline: a workgroup tops its work-item pool up to pool_low by pool_batch items per iteration.  Paths of
+  // one workgroup end their chunks in bursts (they all started together), so an open scene at low spp can ask for a
+  // hundred items in one iteration, and a lane that finds the pool empty pays a global atomic round trip inside the
+  // finish pass: 128 / 256 instead of 24 / 64 tripled such scenes.  Small jobs keep small batches (tail balance).
+  uint32_t pool_low, pool_batch;
   uint32_t trace_spb;                  // segments per k_trace workgroup pass: its per-BSDF lists span that many segments
   int stack_depth;                     // LDS traversal stack entries per lane
 };

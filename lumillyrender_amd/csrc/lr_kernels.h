@@ -1179,7 +1179,6 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
   *next_chunk += chunks;
 }
 
-constexpr int kPoolBatch = 64, kPoolLow = 24;
 #ifndef LR_INLINE_FINISH
 #define LR_INLINE_FINISH 32
 #endif
@@ -1224,7 +1223,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     (void)wave_reserve(&s_retired, r);
   }
   __syncthreads();
-  if (tid == 0) pool_step(st, &pl, kPoolLow, kPoolBatch);           // later top-ups happen in phase 2
+  if (tid == 0) pool_step(st, &pl, st.pool_low, st.pool_batch);     // later top-ups happen in phase 2
   uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0, parity = 0;
 #ifdef LR_STAMP
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
@@ -1289,7 +1288,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     // ---- phase 2: one BSDF-specialised body per list ----
     // nobody draws work items in this phase, so the last thread (its wave has the least shade work: the lists fill
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
-    if (tid == kBlock - 1) pool_step(st, &pl, kPoolLow, kPoolBatch);   // keeps a few iterations of draws; small batches keep the end-of-render tail short
+    if (tid == kBlock - 1) pool_step(st, &pl, st.pool_low, st.pool_batch);   // sized by the host, see DevState
     uint32_t next_chunk = 0;
     if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);

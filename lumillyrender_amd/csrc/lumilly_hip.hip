@@ -459,6 +459,11 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size(); ds.rank_pixel = s.rank_pixel.p;
   ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
+  {
+    const uint64_t per_block = n_items64 / (4ull * std::max<uint32_t>(1u, n_slots / kRSeg));
+    ds.pool_batch = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(64, per_block));
+    ds.pool_low = ds.pool_batch >= 128 ? ds.pool_batch / 2 : 24;
+  }
   DevParams dp; dp.integrator = rp_in.integrator; dp.spp = rp_in.spp; dp.seed = rp_in.seed; dp.depth = rp_in.depth;
   dp.depth_limit = rp_in.depth_limit; dp.no_direct_emitter = rp_in.no_direct_emitter ? 1 : 0;
 
