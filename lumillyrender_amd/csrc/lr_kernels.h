@@ -1179,10 +1179,6 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
   *next_chunk += chunks;
 }
 
-#ifndef LR_INLINE_FINISH
-#define LR_INLINE_FINISH 32
-#endif
-constexpr int kInlineFinish = LR_INLINE_FINISH;
 constexpr int kRSeg = 256;               // slots per resident workgroup (one per thread)
 constexpr int kResidentStateBytes = 6 * kRSeg * 16 + 7 * kRSeg;   // ray_o ray_d thr rad sh_d sh_w(+hit) | 7 byte lists: 25.75 KB, six workgroups per CU
 static_assert(kRSeg <= 256, "slot numbers are stored in bytes");
@@ -1254,23 +1250,13 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
         qid = r.prim < 0 ? kQMiss : (FLAT ? (int)s_qid[r.prim] : (int)sc.prim_qid[r.prim]);
         n_seg += 1;
       }
-      // a ray that left the scene is finished (sky lookup, fold, next camera sample): right here when at least
-      // kInlineFinish lanes of the wave need it (open scenes: the pass is dense enough and saves the hand-off),
-      // otherwise in the finish pass of phase 3
+      // a ray that left the scene queues for the finish pass of phase 3 (sky lookup, fold, next camera sample).
+      // (Finishing dense waves of misses right here was faster only while the work-item pool ran dry in open
+      // scenes; with pools sized for the job the dense finish pass wins everywhere.)
       {
         bool miss = active && qid == kQMiss;
-        if (__builtin_popcountll(__ballot(miss)) >= kInlineFinish) {
-          VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
-          if (miss) v = shade_vertex<kQMiss>(sc, st, rp, slot);
-          if (v.finished) n_done += 1;
-          if (v.sky_fetch) n_sky += 1;
-          bool rr = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample);
-          (void)wave_reserve(&s_retired, rr);
-        } else {
-          uint32_t fidx = wave_reserve(&s_cnt[7], miss);
-          if (miss) finq[fidx] = (uint8_t)slot;
-        }
-        if (miss) active = false;
+        uint32_t fidx = wave_reserve(&s_cnt[7], miss);
+        if (miss) { finq[fidx] = (uint8_t)slot; active = false; }
       }
       uint64_t todo = __ballot(active);
       while (todo) {
