@@ -4,6 +4,9 @@
 // the miss/sky launch) -> shadow.   Paths never leave their slot: a path that ends regenerates
 // the next camera sample of its work item in place, so every slot is live until the work-item
 // dispenser runs dry ("persistent" path slots; workgroups are grid-strided over them).
+// Two pipelines run these stages over the same device functions: the STREAMING kernels below (state in
+// HBM, one launch per stage and iteration) and k_resident (state in LDS, the stages as phases of one
+// launch; chosen for flat scenes and shallow trees, see its header further down).
 //
 //   k_generate   camera.rs:64-115 / :411-476 / :168-188   first camera sample of every slot
 //   k_trace      bvh.rs:130-141 + aabb.rs:74-92 + triangle.rs:69-100 + sphere.rs:42-63
@@ -791,9 +794,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
 // Closest-hit stage of the streaming pipeline.  A workgroup owns `spb` consecutive segments (spb * 512
 // path slots) per pass and hands them to its waves through an LDS dispenser:
 //   * tree scenes: persistent while-while traversal with DYNAMIC RAY FETCH -- a lane whose ray is done
-//     writes its hit, appends its slot to the (segment, BSDF) list and draws the next slot, as soon as
-//     fewer than kRefillBelow lanes of the wave are still walking.  Ray depths differ by 10x in one
-//     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use.
+//     writes its hit, appends its slot to the range's list for its BSDF and draws the next slot, as soon
+//     as at most kRefillBelow lanes of the wave are still walking.  Ray depths differ by 10x in one
+//     wave (box walls vs. the 100k-triangle mesh); without refill the wave idles at ~14 % lane use, and
+//     a pass must be long (up to kMaxGroup segments) or the run-down of its last rays does the same.
 //   * flat scenes (<= 32 primitives): every lane tests every primitive, nothing diverges, plain loop.
 #ifndef LR_TRACE_WAVES
 #define LR_TRACE_WAVES 6
