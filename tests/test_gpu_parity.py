@@ -551,6 +551,31 @@ def test_two_scenes_render_concurrently(dev, oracle):
         scenes[i].close()
 
 
+def test_shared_film_buffer_across_scene_handles(dev):
+    """lr_render writes only the pixels of the tiles it is given, so several handles (one per GPU in
+    production, three on this GPU here) can fill ONE film from concurrent host threads -- what bench.py's ranks do
+    with the film in /dev/shm.  The result equals a single full-frame render bit for bit."""
+    import threading
+    from lumillyrender_amd import host
+    W, H, world = 160, 96, 3
+    desc = load("cbox-spheres.toml", W, H)
+    params = desc.render_params(spp=8, seed=6)
+    one = dev.Scene(desc)
+    want = one.render(params)
+    one.close()
+    film = np.zeros((H, W, 3), dtype=np.float32)
+    scenes = [dev.Scene(desc) for _ in range(world)]
+
+    def work(r):
+        tiles, n = host.tiles(W, H, 32, r, world)
+        scenes[r].render(desc.render_params(spp=8, seed=6), tiles, n, out=film)
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert np.array_equal(film, want)
+    [s.close() for s in scenes]
+
+
 @pytest.mark.parametrize("name", ["cbox-spheres.toml", "two-spheres.toml", "mesh-box.toml"])
 def test_device_built_bvh_gives_the_same_film(dev, oracle, name):
     """an LBVH built on the device (Morton sort + Karras tree + bottom-up fit) instead of the
