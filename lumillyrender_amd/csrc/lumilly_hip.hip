@@ -65,6 +65,8 @@ struct EventPool {
 struct LrScene {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;       // second slot group of the streaming pipeline (render_impl)
+  hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [2] setup done, [3] group 1 batch done
   int n_cus = 0;
   // scene blob
   DevBuf<float4> nodes, prims, flat, shade, emit, texels;
@@ -82,7 +84,7 @@ struct LrScene {
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
   DevBuf<float> film;
-  uint32_t* pinned = nullptr;         // [0..1] retired-slot read-backs, [2..] stats
+  uint32_t* pinned = nullptr;         // [0..3] retired-slot read-backs (two polls x two slot groups), [8..] stats
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
   hipEvent_t t_begin = nullptr, t_end = nullptr;
   EventPool pools[LR_K_COUNT];
@@ -368,13 +370,14 @@ int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
 struct Launcher {
   LrScene& s; bool profile; int iter = 0;
   bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || k == LR_K_RESIDENT || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
-  template <class F> void run(int k, F&& launch) {
+  template <class F> void run(int k, F&& launch, hipStream_t on = nullptr) {
     bool t = timed(k);
     EventPool& p = s.pools[k];
-    if (t) HIP_OK(hipEventRecord(p.a[p.used], s.stream));
+    hipStream_t st = on ? on : s.stream;
+    if (t) HIP_OK(hipEventRecord(p.a[p.used], st));
     launch();
     HIP_OK(hipGetLastError());
-    if (t) { HIP_OK(hipEventRecord(p.b[p.used], s.stream)); p.used++; }
+    if (t) { HIP_OK(hipEventRecord(p.b[p.used], st)); p.used++; }
     s.stats.kernel_launches[k]++;
   }
 };
@@ -486,27 +489,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     HIP_OK(hipFuncSetAttribute(ktrace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_OK(hipFuncSetAttribute(kshadow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  const int g_trace = grid_for(ktrace, s.n_cus, lds, n_seg * kBlock);
-  const int g_shadow = grid_for(kshadow, s.n_cus, lds, n_seg * kBlock);
-  const uint32_t spb_trace = std::min<uint32_t>(kMaxGroup, (n_seg + g_trace - 1) / g_trace);     // segments per workgroup pass
-  const uint32_t spb_shadow = spb_trace;      // k_shade leaves one shadow list per trace range: k_shadow must walk whole ranges
-  ds.trace_spb = spb_trace;
-  const int g_gen = grid_for((const void*)k_generate, s.n_cus, 0, n_seg * kBlock);
-  int g_shade[kNumShadeQueues];
-  const uint32_t n_ranges = (n_seg + spb_trace - 1) / spb_trace;   // k_shade: one workgroup per trace range
-  g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_ranges * kBlock);
-  g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_ranges * kBlock);
-  g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_ranges * kBlock);
-  g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_ranges * kBlock);
-  g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_ranges * kBlock);
-  g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_ranges * kBlock);
-
   DevScene dsc = s.dev;
   dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
-  if (dsc.spill_depth > 0) {
-    s.stack_spill.ensure((size_t)std::max(g_trace, g_shadow) * dsc.spill_depth * kBlock);
-    dsc.stack_spill = s.stack_spill.p;
-  }
   Launcher L{s, profile};
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
   if (n_items > 0 && resident) {
@@ -522,7 +506,62 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {
-    L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(g_gen), dim3(kBlock), 0, st, dsc, ds, dp); });
+    // Two slot groups on two streams: the traversal kernels are latency- and divergence-bound, the shade kernels
+    // bandwidth-bound, so whenever the two groups are out of phase one's k_trace overlaps the other's k_shade
+    // (+10 % on the mesh configs, free-running; chaining the traces with events so that they alternate strictly,
+    // or halving the grids, was slower).  The groups share the item dispenser, the chunk sums and the statistics;
+    // everything indexed by slot or segment is split.  Small jobs and the counting mode keep one group.
+    int G = (!count && n_seg >= 64) ? 2 : 1;
+    if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || (v == 2 && n_seg >= 2)) G = v; }
+    if (G == 2 && !s.stream2) {
+      HIP_OK(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+      for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    struct Group {
+      DevState ds; DevScene dsc; hipStream_t st; uint32_t n_slots, n_seg, spb; int g_trace, g_shadow, g_gen, g_shade[kNumShadeQueues];
+    } grp[2];
+    uint32_t spill_per_group = 0;
+    for (int g = 0; g < G; ++g) {
+      Group& q = grp[g];
+      const uint32_t seg_a = G == 2 ? n_seg / 2 : n_seg;
+      const uint32_t base_seg = g == 0 ? 0u : seg_a;
+      q.n_seg = g == 0 ? seg_a : n_seg - seg_a;
+      q.n_slots = q.n_seg * kSeg;
+      const size_t base = (size_t)base_seg * kSeg;
+      q.st = g == 0 ? st : s.stream2;
+      q.ds = ds;
+      q.ds.ray_o += base; q.ds.ray_d += base; q.ds.hit += base; q.ds.thr += base; q.ds.rad += base; q.ds.acc += base;
+      q.ds.sh_d += base; q.ds.sh_w += base;
+      q.ds.q_shade += (size_t)kNumShadeQueues * base; q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
+      q.ds.q_shadow += (size_t)(kNumShadeQueues - 1) * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
+      q.ds.pool += base_seg;
+      q.ds.n_retired = s.counters.p + 1 + g;
+      q.ds.n_slots = q.n_slots; q.ds.n_seg = q.n_seg;
+      q.g_trace = grid_for(ktrace, s.n_cus, lds, q.n_seg * kBlock);
+      q.g_shadow = grid_for(kshadow, s.n_cus, lds, q.n_seg * kBlock);
+      q.spb = std::min<uint32_t>(kMaxGroup, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
+      q.ds.trace_spb = q.spb;
+      q.g_gen = grid_for((const void*)k_generate, s.n_cus, 0, q.n_seg * kBlock);
+      const uint32_t n_ranges = (q.n_seg + q.spb - 1) / q.spb;                           // k_shade: one workgroup per trace range
+      q.g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_ranges * kBlock);
+      q.dsc = dsc;
+      spill_per_group = std::max<uint32_t>(spill_per_group, (uint32_t)std::max(q.g_trace, q.g_shadow));
+    }
+    if (dsc.spill_depth > 0) {
+      const size_t per = (size_t)spill_per_group * dsc.spill_depth * kBlock;
+      s.stack_spill.ensure(per * G);
+      for (int g = 0; g < G; ++g) grp[g].dsc.stack_spill = s.stack_spill.p + per * g;
+    }
+    if (G == 2) { HIP_OK(hipEventRecord(s.grp_ev[2], st)); HIP_OK(hipStreamWaitEvent(s.stream2, s.grp_ev[2], 0)); }   // uploads, memsets, rank table
+    for (int g = 0; g < G; ++g) {
+      Group& q = grp[g];
+      L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(q.g_gen), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+    }
     const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
     const int kCheck = 8;
     int batch = 0;
@@ -532,34 +571,42 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
     // length statistically, this bounds the loop against a logic error
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
+    auto retired_all = [&](const uint32_t* two) {
+      return two[0] >= grp[0].n_slots && (G == 1 || two[1] >= grp[1].n_slots);
+    };
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
-        if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(g_trace), dim3(kBlock), lds, st, dsc, ds, (const float4*)s.flat.p, spb_trace); });
-        else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(g_trace), dim3(kBlock), lds, st, dsc, ds, (const float4*)s.flat.p, spb_trace); });
-        if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(g_shade[0]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(g_shade[1]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(g_shade[2]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(g_shade[3]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(g_shade[4]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(g_shade[5]), dim3(kBlock), 0, st, dsc, ds, dp); });
-        if (nee) {
-          if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(g_shadow), dim3(kBlock), lds, st, dsc, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
-          else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(g_shadow), dim3(kBlock), lds, st, dsc, ds, mt_mask, (const float4*)s.flat.p, spb_shadow); });
+        for (int g = 0; g < G; ++g) {
+          Group& q = grp[g];
+          if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
+          else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
+          if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(q.g_shade[0]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(q.g_shade[1]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(q.g_shade[2]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(q.g_shade[3]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(q.g_shade[4]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(q.g_shade[5]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (nee) {
+            if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
+            else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
+          }
         }
         L.iter++; S.iterations++;
       }
-      // poll the retired-slot counter one batch behind so the queue never drains
-      HIP_OK(hipMemcpyAsync(&s.pinned[batch & 1], ds.n_retired, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      // poll the retired-slot counters one batch behind so the queue never drains
+      if (G == 2) { HIP_OK(hipEventRecord(s.grp_ev[3], s.stream2)); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[3], 0)); }
+      HIP_OK(hipMemcpyAsync(&s.pinned[(batch & 1) * 2], s.counters.p + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_OK(hipEventRecord(s.poll_ev[batch & 1], st));
       if (batch > 0) {
         HIP_OK(hipEventSynchronize(s.poll_ev[(batch - 1) & 1]));
-        if (s.pinned[(batch - 1) & 1] >= n_slots) done = true;
+        if (retired_all(&s.pinned[((batch - 1) & 1) * 2])) done = true;
       }
       ++batch;
       if (S.iterations > max_iter) fail(LR_EDEVICE, "render loop did not terminate (internal error)");
     }
+    if (G == 2) HIP_OK(hipStreamSynchronize(s.stream2));
     HIP_OK(hipStreamSynchronize(st));
-    if (s.pinned[(batch - 1) & 1] < n_slots) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
+    if (!retired_all(&s.pinned[((batch - 1) & 1) * 2])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
   }
   if (n_pix > 0) {
     int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, n_pix);
@@ -648,6 +695,8 @@ int lr_scene_destroy(LrScene* s) {
   if (s->t_end) (void)hipEventDestroy(s->t_end);
   for (auto& p : s->pools) p.destroy();
   if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  for (auto& e : s->grp_ev) if (e) (void)hipEventDestroy(e);
   delete s;
   return LR_OK;
 }
