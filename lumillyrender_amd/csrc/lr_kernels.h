@@ -195,15 +195,19 @@ template <bool SHADOW>
 LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n) {
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
+  // the rows of primitive k+1 are requested before primitive k is tested: a leaf of n primitives costs one exposed
+  // fetch round trip plus n tests, not n round trips
+  const float4* q = sc.prims + 3 * (size_t)first;
+  float4 n0 = q[0], n1 = q[1], n2 = q[2];
   for (uint32_t k = 0; k < count; ++k) {
-    const float4* q = sc.prims + 3 * (size_t)(first + k);
-    float4 q0 = q[0], q1 = q[1];
+    float4 q0 = n0, q1 = n1, q2 = n2;
+    if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
     uint32_t idw = __float_as_uint(q0.w);
     int id = (int)(idw & 0x7fffffffu);
     float t; bool hit;
     s.tests += 1;
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
-    else { float4 q2 = q[2]; hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t); }
+    else hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t);
     if (!hit) continue;
     if (SHADOW) {
       float diff = t - s.dist;
