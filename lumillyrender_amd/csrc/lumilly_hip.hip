@@ -425,8 +425,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const int resident_per_cu = std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
   // streaming: enough slots that a k_trace workgroup pass covers many rays per lane (the run-down of a pass's last
   // rays is what idles lanes: 1 M slots = 4 rays per lane left 23 % of the lanes busy in a node step), but no more
-  // than 1/8 of the work items so that the render as a whole still has many iterations; 136 B of state per slot
-  const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(16u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
+  // than 1/8 of the work items so that the render as a whole still has many iterations; 136 B of state per slot (<= 32 M slots)
+  const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(32u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : stream_slots);
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
