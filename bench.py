@@ -231,6 +231,10 @@ def main():
                 "timed_launches": acc["kernel_timed"][dom],
                 # the MEASURED HBM rate next to the algorithmic one (PMC bytes of profiles/traffic.json over this run's launch time)
                 "measured_hbm_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None,
+                "note": ("the algorithmic bytes are what a wavefront design streams per sample (SURVEY 8d); the resident kernel keeps "
+                         "them in LDS / the scalar cache, so frac is not HBM saturation: its real bound is VALU issue "
+                         "(PMC: 69 % of the wave64 issue rate, DESIGN.md section 6)") if dom == abi.LR_K_RESIDENT else
+                        "streaming pipeline: path state moves through HBM / Infinity Cache every iteration",
             }
             out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
                                             for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
