@@ -243,6 +243,33 @@ def test_edge_cases(dev, oracle):
     scene.close()
 
 
+def test_row_stride_and_ragged_tiles(dev):
+    """lr_render writes rows `row_stride_floats` apart (an Img with padding, or a window of a larger canvas) and takes
+    any set of non-overlapping rectangles, not only the 64x64 grid: the assembled window equals a plain render."""
+    import ctypes as C
+    from lumillyrender_amd import abi
+    W, H = 70, 45
+    desc = load("cbox-spheres.toml", W, H)
+    scene = dev.Scene(desc)
+    params = desc.render_params(spp=4, seed=8)
+    want = scene.render(params)
+    rects = [(0, 0, 33, 20), (33, 0, 37, 7), (33, 7, 37, 13), (0, 20, 70, 1), (0, 21, 1, 24), (1, 21, 69, 24)]   # x0, y0, w, h: a ragged cover
+    assert sum(w * h for _, _, w, h in rects) == W * H
+    tiles = (abi.LrTile * len(rects))()
+    for t, (x0, y0, w, h) in zip(tiles, rects):
+        t.x0, t.y0, t.w, t.h = x0, y0, w, h
+    stride = W * 3 + 11                                              # floats per row of the destination
+    canvas = np.full((H + 2, stride), -7.0, dtype=np.float32)
+    rc = dev.lib().lr_render(scene._h, C.byref(params), tiles, len(rects), canvas[1:].ctypes.data_as(C.POINTER(C.c_float)), stride)
+    assert rc == 0
+    got = canvas[1:1 + H, :W * 3].reshape(H, W, 3)
+    assert np.array_equal(got, want)
+    assert (canvas[0] == -7).all() and (canvas[-1] == -7).all() and (canvas[1:1 + H, W * 3:] == -7).all()   # nothing outside the window
+    # a stride smaller than a row is refused
+    assert dev.lib().lr_render(scene._h, C.byref(params), tiles, len(rects), canvas.ctypes.data_as(C.POINTER(C.c_float)), W * 3 - 1) == abi.LR_EINVAL
+    scene.close()
+
+
 # ---- committed golden crops, larger scenes, remaining cameras / materials ------------------------------
 
 def test_golden_fixtures(dev):
