@@ -408,7 +408,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (npix64 > (uint64_t)W * (uint64_t)H) fail(LR_EINVAL, "tiles overlap (more tile pixels than film pixels)");
   const uint32_t n_pix = (uint32_t)npix64;
   // chunks: a function of spp ONLY, so the image does not depend on tiling, slot count or GPU count
-  uint32_t n_chunks = (uint32_t)std::min(64, std::max(1, rp_in.spp / 8));
+  // up to 1024 spp: chunks of >= 8 samples, at most 64; beyond: chunks of >= 16 samples, at most 256 -- a slot ends the
+  // render inside its last chunk, so the chunk length is the tail of the render (weak scaling raises spp per pixel)
+  uint32_t n_chunks = rp_in.spp <= 1024 ? (uint32_t)std::min(64, std::max(1, rp_in.spp / 8)) : (uint32_t)std::min(256, rp_in.spp / 16);
   uint32_t chunk_spp = ((uint32_t)rp_in.spp + n_chunks - 1) / n_chunks;
   n_chunks = ((uint32_t)rp_in.spp + chunk_spp - 1) / chunk_spp;
   uint64_t n_items64 = (uint64_t)n_pix * n_chunks;
