@@ -89,7 +89,8 @@ struct LrScene {
   hipEvent_t t_begin = nullptr, t_end = nullptr;
   EventPool pools[LR_K_COUNT];
   LrStats stats;
-  std::vector<float> host_film;
+  float* host_film = nullptr;           // pinned staging copy of the film (lr_render), host_film_cap floats
+  size_t host_film_cap = 0;
 };
 
 namespace {
@@ -692,6 +693,7 @@ int lr_scene_destroy(LrScene* s) {
   s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
   s->stats_dev.release(); s->film.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
+  if (s->host_film) (void)hipHostFree(s->host_film);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
   if (s->t_begin) (void)hipEventDestroy(s->t_begin);
   if (s->t_end) (void)hipEventDestroy(s->t_end);
@@ -717,13 +719,19 @@ int lr_render(LrScene* s, const LrRenderParams* params, const LrTile* tiles, int
     if (row_stride_floats < (size_t)s->film_w * 3) fail(LR_EINVAL, "row stride smaller than one film row");
     render_impl(*s, *params, tiles, n_tiles);
     const int W = s->film_w, H = s->film_h;
-    s->host_film.resize((size_t)W * H * 3);
-    HIP_OK(hipMemcpyAsync(s->host_film.data(), s->film.p, s->host_film.size() * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    const size_t n_film = (size_t)W * H * 3;
+    if (s->host_film_cap < n_film) {                                // pinned: the device-to-host copy runs at link speed, not through a bounce buffer
+      if (s->host_film) (void)hipHostFree(s->host_film);
+      s->host_film = nullptr; s->host_film_cap = 0;
+      HIP_OK(hipHostMalloc((void**)&s->host_film, n_film * sizeof(float)));
+      s->host_film_cap = n_film;
+    }
+    HIP_OK(hipMemcpyAsync(s->host_film, s->film.p, n_film * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
     for (int i = 0; i < n_tiles; ++i) {                            // only tile pixels are written (Img::set per job, main.rs:129-132)
       const LrTile& t = tiles[i];
       for (int y = t.y0; y < t.y0 + t.h; ++y)
-        std::memcpy(rgb_out + (size_t)y * row_stride_floats + (size_t)t.x0 * 3, s->host_film.data() + ((size_t)y * W + t.x0) * 3, (size_t)t.w * 3 * sizeof(float));
+        std::memcpy(rgb_out + (size_t)y * row_stride_floats + (size_t)t.x0 * 3, s->host_film + ((size_t)y * W + t.x0) * 3, (size_t)t.w * 3 * sizeof(float));
     }
   })
 }
