@@ -182,6 +182,8 @@ typedef struct LrStats {
   double   render_ms;                /* wall time of the last lr_render, device work only    */
   double   upload_ms;                /* lr_scene_create                                      */
   double   bvh_build_ms;             /* device LBVH build inside lr_scene_create (0 = host tree) */
+  uint64_t path_slots;               /* path-state slots the last render ran with                */
+  uint64_t pipeline;                 /* 1 = resident (one launch, state in LDS), 0 = streaming   */
 } LrStats;
 
 typedef struct LrScene LrScene;      /* opaque */

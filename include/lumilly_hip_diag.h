@@ -1,0 +1,52 @@
+/*
+ * lumilly_hip_diag.h -- DIAGNOSTIC entry points of liblumilly_hip.so.
+ *
+ * Not part of the drop-in surface (include/lumilly_hip.h is the reference-shaped boundary): these run single
+ * device functions of the render path on caller data so that the parity tests can compare them, bit for bit,
+ * with the CPU oracle -- the device-side counterpart of the reference's inline unit tests
+ * (src/triangle.rs:152-236, src/util.rs:45-82).  Same conventions: plain pointers and sizes, 0 / LR_E* return
+ * codes, never throw.
+ */
+#ifndef LUMILLY_HIP_DIAG_H
+#define LUMILLY_HIP_DIAG_H
+
+#include "lumilly_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The deterministic math spec on the device (csrc/lr_math.h): out[i] = fn(a[i] [, b[i]]).
+ * fn: 0 sin, 1 cos, 2 acos, 3 atan2(a, b), 4 pow(a, b), 5 exp, 6 fmod_pos(a, b), 7 a / b, 8 sqrt,
+ *     9 Lambert grid level at (a, b) (lambert.rs:66-90).  b may be NULL for the unary ones. */
+int lr_selftest_math(int device, int fn, const float* a, const float* b, float* out, int n);
+
+/* Exhaustive check of the five-instruction exact reciprocal used by the triangle test against the IEEE quotient
+ * over every float whose biased exponent lies in [lo_exp, hi_exp]: out4 = {mismatches of the 2-step form,
+ * mismatches of the 3-step form, one offending bit pattern each}. */
+int lr_selftest_rcp(int device, uint32_t lo_exp, uint32_t hi_exp, uint64_t* out4);
+
+/* The counter-based generator: out4[4*i..] = the four draws of block[i] of (seed, pixel[i], sample[i]). */
+int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint32_t* sample, const uint32_t* block,
+                    float* out4, int n);
+
+/* Closest hit of n rays through the scene's traversal path (flat loop or 4-wide tree, as lr_render would choose):
+ * prim_out[i] = primitive index or -1, t_out[i] = distance (0 on a miss).  Replaces bvh.rs:130-141 for a batch. */
+int lr_selftest_intersect(LrScene* scene, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out);
+
+/* The DEFINITION of the closest hit on the device: every ray against EVERY primitive (no tree, no boxes), minimum
+ * distance, ties to the lowest primitive index -- bvh.rs:131-141's "min over all candidates" with the candidate set
+ * widened to the whole scene.  Same primitive tests as the render path.  O(n * n_prims). */
+int lr_selftest_brute(LrScene* scene, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out);
+
+/* Emitter pick of objects.rs:37-51 on the device: for n uniform draws xi in [0,1), k_out[i] = index (into the scene's
+ * emitter list, instance order) of the emitter chosen by roulette = total_area * xi[i]. */
+int lr_selftest_emitter_pick(LrScene* scene, int n, const float* xi, int32_t* k_out);
+
+/* Sky::radiance (sky.rs:13-21 uniform, :57-78 IBL nearest texel) for n unit directions: rgb_out[3*i..]. */
+int lr_selftest_sky(LrScene* scene, int n, const float* dirs, float* rgb_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUMILLY_HIP_DIAG_H */

@@ -97,6 +97,8 @@ class LrStats(C.Structure):
         ("render_ms", C.c_double),
         ("upload_ms", C.c_double),
         ("bvh_build_ms", C.c_double),
+        ("path_slots", u64),
+        ("pipeline", u64),
     ]
 
 

@@ -88,6 +88,7 @@ struct DevState {
   unsigned long long* stats;           // kStatShards * kStatStride
   float4* partial;                     // n_items chunk sums
   float*  film;                        // W*H*3
+  float*  packed;                      // n_pix*3 in pixel-rank order, or null (lr_render's read-back source)
   const int4* tiles;                   // x0, y0, w, h
   const uint32_t* tile_prefix;         // n_tiles + 1
   uint32_t* rank_pixel;                // n_pix: film pixel of every pixel rank (k_rank_table), one load instead of a search per work item

@@ -629,10 +629,9 @@ LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
 // ------------------------------------------------------------------------------------------
 // emitter sampling  (objects.rs:37-51, triangle.rs:140-149, sphere.rs:79-84, util.rs:108-116)
 // ------------------------------------------------------------------------------------------
-LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float* pdf) {
-  float roulette = sc.emission_area * d.v[1];
+// objects.rs:37-51: the first emitter k (instance order) with roulette <= cumulative area
+LR_DEV int emitter_index(const DevScene& sc, float roulette) {
   int k = 0;
-  // first k with roulette <= cumulative area (the host accumulates in the reference's order)
   int n = sc.n_emitters;
   if (n <= 8) {
     // the cumulative areas are nondecreasing, so "first k with roulette <= cum[k]" is a count; the rows are
@@ -640,10 +639,18 @@ LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float
     const ConstRow* er = (const ConstRow*)sc.emit;
     for (int j = 0; j < n - 1; ++j) k += !(roulette <= er[3 * j + 2].w) ? 1 : 0;
   } else {
+    // emissive meshes (scene_loader.rs:254-262 binds a light to every triangle of an object): binary search for the
+    // same "first k" -- the sums are nondecreasing, so it finds what the reference's linear scan finds; the last
+    // emitter catches a roulette that rounding left above the final sum (the reference would panic there, objects.rs:50)
     int lo = 0, hi = n - 1;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (roulette <= sc.emit[3 * mid + 2].w) hi = mid; else lo = mid + 1; }
     k = lo;
   }
+  return k;
+}
+LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float* pdf) {
+  float roulette = sc.emission_area * d.v[1];
+  int k = emitter_index(sc, roulette);
   float4 e0 = sc.emit[3 * k], e1 = sc.emit[3 * k + 1], e2 = sc.emit[3 * k + 2];
   if (__float_as_uint(e0.w) == LR_PRIM_TRIANGLE) {
     float u = d.v[2], v = d.v[3];
@@ -1359,6 +1366,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, De
     uint32_t pixel = item_pixel(st, sc.cam, rank);
     float* o = st.film + (size_t)pixel * 3;
     o[0] = px.x; o[1] = px.y; o[2] = px.z;
+    if (st.packed) { float* q = st.packed + (size_t)rank * 3; q[0] = px.x; q[1] = px.y; q[2] = px.z; }
   }
 }
 
@@ -1444,6 +1452,38 @@ __global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, cons
   V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
   TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, nullptr);
   prim_out[i] = r.prim; t_out[i] = r.prim >= 0 ? r.t : 0.0f;
+}
+
+// bvh.rs:131-141 with the candidate set widened to every primitive: the definition the tree must reproduce.  The loop
+// index is wave-uniform, so the rows arrive by scalar loads; tri_test / sphere_test are the render path's own.
+__global__ void __launch_bounds__(kBlock) k_selftest_brute(const float4* __restrict__ prims, int n_prims, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  const int ii = valid ? i : n - 1;
+  V3 o = v3(origins[3 * (size_t)ii], origins[3 * (size_t)ii + 1], origins[3 * (size_t)ii + 2]);
+  V3 d = v3(dirs[3 * (size_t)ii], dirs[3 * (size_t)ii + 1], dirs[3 * (size_t)ii + 2]);
+  float best = 3.0e38f; int bp = -1;
+  const ConstRow* rows = (const ConstRow*)prims;
+  for (int k = 0; k < n_prims; ++k) {
+    float4 q0 = row4(rows[3 * (size_t)k]), q1 = row4(rows[3 * (size_t)k + 1]), q2 = row4(rows[3 * (size_t)k + 2]);
+    uint32_t idw = __float_as_uint(q0.w);
+    int id = (int)(idw & 0x7fffffffu);
+    float t = 0.0f; bool hit;
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
+    if (hit && (t < best || (t == best && id < bp))) { best = t; bp = id; }
+  }
+  if (valid) { prim_out[i] = bp; t_out[i] = bp >= 0 ? best : 0.0f; }
+}
+__global__ void k_selftest_sky(DevScene sc, const float* dirs, float* rgb, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 c = sky_radiance(sc, v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]));
+  rgb[3 * (size_t)i] = c.x; rgb[3 * (size_t)i + 1] = c.y; rgb[3 * (size_t)i + 2] = c.z;
+}
+__global__ void k_selftest_emitter_pick(DevScene sc, const float* xi, int* k_out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) k_out[i] = emitter_index(sc, sc.emission_area * xi[i]);
 }
 
 }  // namespace lr

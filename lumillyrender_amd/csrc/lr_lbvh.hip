@@ -206,7 +206,12 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
                float4* d_nodes, float4* d_prims, int* height_out, double* ms_out, std::string& err) {
   if (n < 2) { err = "lbvh_build needs at least two primitives"; return LR_EINVAL; }
   Tmp tmp;
-  hipEvent_t e0, e1; LB_OK(hipEventCreate(&e0)); LB_OK(hipEventCreate(&e1));
+  struct Events {                                                  // destroyed on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  LB_OK(hipEventCreate(&ev.a)); LB_OK(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   LrPrimitive* d_in = tmp.get<LrPrimitive>(n);
   float* boxes = tmp.get<float>((size_t)n * 6);
   float* node_boxes = tmp.get<float>((size_t)n * 6);
@@ -256,7 +261,6 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
   LB_OK(hipMemcpyAsync(&h, height, sizeof(int), hipMemcpyDeviceToHost, st));
   LB_OK(hipStreamSynchronize(st));
   float ms = 0.0f; LB_OK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *height_out = h; *ms_out = ms;
   return LR_OK;
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/lumilly_hip.h"
+#include "../../include/lumilly_hip_diag.h"
 #include "lr_kernels.h"
 #include "lr_lbvh.h"
 
@@ -31,9 +32,14 @@ void hip_check(hipError_t e, const char* what) {
 }
 #define HIP_OK(x) hip_check((x), #x)
 
+// Owning device buffer: released by the destructor, so a temporary never leaks on an error path (every HIP_OK throws).
 template <class T>
 struct DevBuf {
   T* p = nullptr; size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
   void ensure(size_t count) {
     if (count <= n && p) return;
     release();
@@ -76,6 +82,7 @@ struct LrScene {
   int stack_depth = 2;
   double bvh_build_ms = 0.0;           // device LBVH build time (0 when the host supplied the tree)
   int film_w = 0, film_h = 0;
+  int n_prims = 0;
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
@@ -84,6 +91,7 @@ struct LrScene {
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
   DevBuf<float> film;
+  DevBuf<float> packed;                // the rendered tiles' pixels in pixel-rank order (lr_render reads back only these)
   uint32_t* pinned = nullptr;         // [0..3] retired-slot read-backs (two polls x two slot groups), [8..] stats
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
   hipEvent_t t_begin = nullptr, t_end = nullptr;
@@ -255,6 +263,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   } else {
     nodes.assign((size_t)d.n_bvh_nodes * 4, make_float4(0, 0, 0, 0));
     std::vector<char> seen((size_t)np, 0);
+    std::vector<char> referenced((size_t)d.n_bvh_nodes, 0);        // a tree, not a DAG: every inner node has exactly one parent
     for (int i = 0; i < d.n_bvh_nodes; ++i) {
       const LrBvhNode& n = d.bvh_nodes[i];
       nodes[4 * i] = make_float4(n.x[0], n.x[1], n.x[2], n.x[3]);
@@ -263,7 +272,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       nodes[4 * i + 3] = make_float4(__builtin_bit_cast(float, n.child[0]), __builtin_bit_cast(float, n.child[1]), 0.0f, 0.0f);
       for (int c = 0; c < 2; ++c) {
         int ch = n.child[c];
-        if (ch >= 0) { if (ch >= d.n_bvh_nodes || ch <= i) fail(LR_EINVAL, "BVH child index out of order"); continue; }
+        if (ch >= 0) {
+          if (ch >= d.n_bvh_nodes || ch <= i) fail(LR_EINVAL, "BVH child index out of order");
+          if (referenced[ch]) fail(LR_EINVAL, "BVH node referenced by two parents");     // a shared subtree would be expanded once per parent (exponential)
+          referenced[ch] = 1;
+          continue;
+        }
         uint32_t enc = (uint32_t)~ch, first = enc >> 3, count = enc & 7u;
         if ((uint64_t)first + count > (uint64_t)np) fail(LR_EINVAL, "BVH leaf range out of bounds");
         for (uint32_t k = first; k < first + count; ++k) {
@@ -284,6 +298,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       }
     }
     for (int i = 0; i < np; ++i) if (!seen[i]) fail(LR_EINVAL, "BVH does not reference every primitive");
+    for (int i = 1; i < d.n_bvh_nodes; ++i) if (!referenced[i]) fail(LR_EINVAL, "BVH node without a parent");
     if (d.bvh_max_depth < 1 || d.bvh_max_depth > 96) fail(LR_EINVAL, "bvh_max_depth out of range (1..96)");
     s.stack_depth = d.bvh_max_depth + 1;
   }
@@ -357,6 +372,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     dc.weight2 = c.sensor_sensitivity / (sensor_pdf * aperture_pdf);
   }
   s.film_w = c.resolution[0]; s.film_h = c.resolution[1];
+  s.n_prims = np;
 }
 
 int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
@@ -389,7 +405,7 @@ int stack_lds_limit() {
   return kStackLdsMax;
 }
 
-void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, int n_tiles) {
+void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, int n_tiles, bool want_packed = false) {
   if (rp_in.spp <= 0) fail(LR_EINVAL, "spp must be positive");
   if (rp_in.integrator != LR_INTEGRATOR_PT && rp_in.integrator != LR_INTEGRATOR_PT_DIRECT) fail(LR_EINVAL, "unknown integrator");
   if (rp_in.depth < 0 || rp_in.depth_limit < 0) fail(LR_EINVAL, "negative depth");
@@ -407,6 +423,21 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   }
   prefix.push_back((uint32_t)npix64);
   if (npix64 > (uint64_t)W * (uint64_t)H) fail(LR_EINVAL, "tiles overlap (more tile pixels than film pixels)");
+  {
+    // the header promises disjoint tiles: a pixel in two tiles would be rendered twice and resolved twice.  Sweep over
+    // the tiles sorted by first row; only tiles whose row ranges intersect are compared.
+    std::vector<int> ord(tl.size());
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return tl[a].y < tl[b].y || (tl[a].y == tl[b].y && tl[a].x < tl[b].x); });
+    for (size_t i = 0; i < ord.size(); ++i) {
+      const int4 a = tl[ord[i]];
+      for (size_t j = i + 1; j < ord.size(); ++j) {
+        const int4 b = tl[ord[j]];
+        if (b.y >= a.y + a.w) break;                                // int4 {x0, y0, w, h}: .z = w, .w = h
+        if (b.x < a.x + a.z && a.x < b.x + b.z) fail(LR_EINVAL, "tiles overlap");
+      }
+    }
+  }
   const uint32_t n_pix = (uint32_t)npix64;
   // chunks: a function of spp ONLY, so the image does not depend on tiling, slot count or GPU count
   // up to 1024 spp: chunks of >= 8 samples, at most 64; beyond: chunks of >= 16 samples, at most 256 -- a slot ends the
@@ -461,7 +492,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p;
   ds.q_shade = s.q_shade.p; ds.c_shade = s.c_shade.p; ds.q_shadow = s.q_shadow.p; ds.c_shadow = s.c_shadow.p; ds.pool = s.pool.p;
   ds.next_item = s.counters.p; ds.n_retired = s.counters.p + 1;
-  ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p;
+  if (want_packed) s.packed.ensure((size_t)std::max<uint32_t>(n_pix, 1) * 3);
+  ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p; ds.packed = want_packed ? s.packed.p : nullptr;
   ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size(); ds.rank_pixel = s.rank_pixel.p;
   ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
@@ -476,6 +508,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   LrStats& S = s.stats;
   double keep_upload = S.upload_ms, keep_bvh = S.bvh_build_ms;
   std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload; S.bvh_build_ms = keep_bvh;
+  S.path_slots = n_slots; S.pipeline = resident ? 1 : 0;
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
@@ -648,7 +681,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   try { __VA_ARGS__; return LR_OK; }                                                    \
   catch (const ApiError& e) { g_err = e.msg; return e.code; }                           \
   catch (const std::bad_alloc&) { g_err = "out of host memory"; return LR_ENOMEM; }     \
-  catch (const std::exception& e) { g_err = e.what(); return LR_EINVAL; }
+  catch (const std::exception& e) { g_err = e.what(); return LR_EINVAL; }           \
+  catch (...) { g_err = "unknown error"; return LR_EINVAL; }
 
 extern "C" {
 
@@ -682,6 +716,8 @@ int lr_scene_create(int device, const LrSceneDesc* desc, LrScene** out) {
     return LR_OK;
   } catch (const ApiError& e) { g_err = e.msg; if (s) lr_scene_destroy(s); return e.code; }
   catch (const std::bad_alloc&) { g_err = "out of host memory"; if (s) lr_scene_destroy(s); return LR_ENOMEM; }
+  catch (const std::exception& e) { g_err = e.what(); if (s) lr_scene_destroy(s); return LR_EINVAL; }      // e.g. std::length_error from a vector sized by a corrupt count
+  catch (...) { g_err = "unknown error"; if (s) lr_scene_destroy(s); return LR_EINVAL; }                   // nothing crosses the extern "C" boundary
 }
 
 int lr_scene_destroy(LrScene* s) {
@@ -691,7 +727,7 @@ int lr_scene_destroy(LrScene* s) {
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
   s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
-  s->stats_dev.release(); s->film.release();
+  s->stats_dev.release(); s->film.release(); s->packed.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->host_film) (void)hipHostFree(s->host_film);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
@@ -717,21 +753,27 @@ int lr_render(LrScene* s, const LrRenderParams* params, const LrTile* tiles, int
   LR_TRY({
     if (!s || !params || !rgb_out) fail(LR_EINVAL, "null argument");
     if (row_stride_floats < (size_t)s->film_w * 3) fail(LR_EINVAL, "row stride smaller than one film row");
-    render_impl(*s, *params, tiles, n_tiles);
-    const int W = s->film_w, H = s->film_h;
-    const size_t n_film = (size_t)W * H * 3;
-    if (s->host_film_cap < n_film) {                                // pinned: the device-to-host copy runs at link speed, not through a bounce buffer
+    render_impl(*s, *params, tiles, n_tiles, true);
+    // read back only the pixels this call rendered (1/world of the film for a rank of a multi-GPU job): k_resolve left
+    // them packed in pixel-rank order = tile list order, row-major inside a tile
+    size_t n_val = 0;
+    for (int i = 0; i < n_tiles; ++i) if (tiles[i].w > 0 && tiles[i].h > 0) n_val += (size_t)tiles[i].w * tiles[i].h * 3;
+    if (s->host_film_cap < n_val) {                                 // pinned: the device-to-host copy runs at link speed, not through a bounce buffer
       if (s->host_film) (void)hipHostFree(s->host_film);
       s->host_film = nullptr; s->host_film_cap = 0;
-      HIP_OK(hipHostMalloc((void**)&s->host_film, n_film * sizeof(float)));
-      s->host_film_cap = n_film;
+      HIP_OK(hipHostMalloc((void**)&s->host_film, n_val * sizeof(float)));
+      s->host_film_cap = n_val;
     }
-    HIP_OK(hipMemcpyAsync(s->host_film, s->film.p, n_film * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    if (n_val > 0) {
+      HIP_OK(hipMemcpyAsync(s->host_film, s->packed.p, n_val * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+      HIP_OK(hipStreamSynchronize(s->stream));
+    }
+    const float* src = s->host_film;
     for (int i = 0; i < n_tiles; ++i) {                            // only tile pixels are written (Img::set per job, main.rs:129-132)
       const LrTile& t = tiles[i];
-      for (int y = t.y0; y < t.y0 + t.h; ++y)
-        std::memcpy(rgb_out + (size_t)y * row_stride_floats + (size_t)t.x0 * 3, s->host_film + ((size_t)y * W + t.x0) * 3, (size_t)t.w * 3 * sizeof(float));
+      if (t.w <= 0 || t.h <= 0) continue;
+      for (int y = t.y0; y < t.y0 + t.h; ++y, src += (size_t)t.w * 3)
+        std::memcpy(rgb_out + (size_t)y * row_stride_floats + (size_t)t.x0 * 3, src, (size_t)t.w * 3 * sizeof(float));
     }
   })
 }
@@ -753,7 +795,6 @@ int lr_film_quantize(LrScene* s, int mode, float gamma, uint8_t* out, size_t row
     HIP_OK(hipMemcpyAsync(host.data(), q.p, host.size(), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
     for (int y = 0; y < H; ++y) std::memcpy(out + (size_t)y * row_stride_bytes, host.data() + (size_t)y * W * bpp, (size_t)W * bpp);
-    q.release();
   })
 }
 
@@ -775,7 +816,6 @@ int lr_selftest_math(int device, int fn, const float* a, const float* b, float* 
     if (n > 0) hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, 0, fn, da.p, b ? db.p : (const float*)nullptr, dout.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    da.release(); db.release(); dout.release();
   })
 }
 int lr_selftest_rcp(int device, uint32_t lo_exp, uint32_t hi_exp, uint64_t* out4) {
@@ -787,7 +827,6 @@ int lr_selftest_rcp(int device, uint32_t lo_exp, uint32_t hi_exp, uint64_t* out4
     hipLaunchKernelGGL(k_selftest_rcp, dim3(256 * 16), dim3(256), 0, 0, lo_exp, hi_exp, d.p);
     HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out4, d.p, 32, hipMemcpyDeviceToHost));
-    d.release();
   })
 }
 int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint32_t* sample, const uint32_t* block, float* out4, int n) {
@@ -802,7 +841,6 @@ int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint
     if (n > 0) hipLaunchKernelGGL(k_selftest_rng, dim3((n + 255) / 256), dim3(256), 0, 0, seed, dp.p, dsm.p, dbk.p, dout.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out4, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
-    dp.release(); dsm.release(); dbk.release(); dout.release();
   })
 }
 int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
@@ -823,7 +861,46 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    dor.release(); ddr.release(); dt.release(); dpr.release();
+  })
+}
+
+int lr_selftest_brute(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
+  LR_TRY({
+    if (!s || !origins || !dirs || !prim_out || !t_out || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<float> dor, ddr, dt; DevBuf<int> dpr;
+    dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
+    HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_brute, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, (const float4*)s->prims.p, s->n_prims, dor.p, ddr.p, dpr.p, dt.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  })
+}
+int lr_selftest_sky(LrScene* s, int n, const float* dirs, float* rgb_out) {
+  LR_TRY({
+    if (!s || !dirs || !rgb_out || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<float> dd, dc;
+    dd.ensure((size_t)n * 3); dc.ensure((size_t)n * 3);
+    HIP_OK(hipMemcpy(dd.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_sky, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, dd.p, dc.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(rgb_out, dc.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  })
+}
+int lr_selftest_emitter_pick(LrScene* s, int n, const float* xi, int32_t* k_out) {
+  LR_TRY({
+    if (!s || !xi || !k_out || n < 0) fail(LR_EINVAL, "bad argument");
+    if (s->dev.n_emitters <= 0) fail(LR_EINVAL, "scene has no emitters");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<float> dx; DevBuf<int> dk;
+    dx.ensure(n); dk.ensure(n);
+    HIP_OK(hipMemcpy(dx.p, xi, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_emitter_pick, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, dx.p, dk.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(k_out, dk.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   })
 }
 

@@ -42,6 +42,9 @@ def lib():
     up = C.POINTER(C.c_uint32)
     l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
     l.lr_selftest_intersect.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    l.lr_selftest_brute.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    l.lr_selftest_emitter_pick.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int32)]
+    l.lr_selftest_sky.argtypes = [vp, C.c_int, fp, fp]
     if hasattr(l, "lr_selftest_rcp"):                      # diagnostics entry point; older builds (tools/sweep.sh) lack it
         l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
@@ -95,19 +98,39 @@ class Scene:
         except Exception:
             pass
 
-    def render(self, params, tiles=None, n_tiles=None, out=None):
-        """Render `tiles` (default: the whole film) into an (H, W, 3) f32 array."""
+    def _tile_args(self, tiles, n_tiles):
         if tiles is None:
             tiles = (abi.LrTile * 1)()
             tiles[0].x0, tiles[0].y0, tiles[0].w, tiles[0].h = 0, 0, self.width, self.height
-            n_tiles = 1
+            return tiles, 1
+        if n_tiles is None:
+            n_tiles = len(tiles)
+        if n_tiles < 0 or n_tiles > len(tiles):
+            raise ValueError(f"n_tiles = {n_tiles} but the tile array holds {len(tiles)}")
+        return tiles, n_tiles
+
+    def _check_film(self, out):
+        """The native side writes (H, W, 3) f32 rows of the film size captured at scene creation: anything else
+        (another dtype, a strided view, a film resized after Scene()) would be written out of bounds."""
+        if not isinstance(out, np.ndarray) or out.dtype != np.float32:
+            raise ValueError("film must be a float32 numpy array")
+        if out.shape != (self.height, self.width, 3):
+            raise ValueError(f"film shape {out.shape} does not match the scene's film ({self.height}, {self.width}, 3)")
+        if not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("film must be C-contiguous and writable")
+
+    def render(self, params, tiles=None, n_tiles=None, out=None):
+        """Render `tiles` (default: the whole film) into an (H, W, 3) f32 array."""
+        tiles, n_tiles = self._tile_args(tiles, n_tiles)
         if out is None:
             out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        self._check_film(out)
         _check(lib().lr_render(self._h, C.byref(params), tiles, n_tiles, _fptr(out), self.width * 3))
         return out
 
-    def render_device(self, params, tiles, n_tiles):
+    def render_device(self, params, tiles=None, n_tiles=None):
         """Render and leave the film in HBM; returns the device pointer (int)."""
+        tiles, n_tiles = self._tile_args(tiles, n_tiles)
         p = C.c_void_p()
         _check(lib().lr_render_device(self._h, C.byref(params), tiles, n_tiles, C.byref(p)))
         return p.value
@@ -115,6 +138,8 @@ class Scene:
     def quantize(self, mode="rgb8", gamma=2.2):
         """Film output stage on the device for the last render: (H, W, 3) uint8 with the reference's
         gamma/truncation (main.rs:171-173) or (H, W, 4) Radiance RGBE bytes."""
+        if mode not in ("rgb8", "rgbe"):
+            raise ValueError("mode must be 'rgb8' or 'rgbe'")
         bpp = 3 if mode == "rgb8" else 4
         out = np.empty((self.height, self.width, bpp), dtype=np.uint8)
         _check(lib().lr_film_quantize(self._h, 0 if mode == "rgb8" else 1, gamma, out.ctypes.data_as(C.POINTER(C.c_uint8)), self.width * bpp))
@@ -125,14 +150,40 @@ class Scene:
         _check(lib().lr_get_stats(self._h, C.byref(s)))
         return s
 
-    def intersect(self, origins, dirs):
+    @staticmethod
+    def _rays(origins, dirs):
         o = np.ascontiguousarray(origins, dtype=np.float32)
         d = np.ascontiguousarray(dirs, dtype=np.float32)
+        if o.ndim != 2 or o.shape[1] != 3 or d.shape != o.shape:
+            raise ValueError(f"origins / dirs must both be (n, 3) arrays, got {o.shape} and {d.shape}")
+        return o, d
+
+    def intersect(self, origins, dirs, brute=False):
+        """Closest hit per ray: through the traversal path lr_render uses (flat loop or tree), or with brute=True
+        against every primitive (the definition, bvh.rs:131-141).  Returns (primitive index or -1, distance)."""
+        o, d = self._rays(origins, dirs)
         n = o.shape[0]
         prim = np.empty(n, dtype=np.int32)
         t = np.empty(n, dtype=np.float32)
-        _check(lib().lr_selftest_intersect(self._h, n, _fptr(o), _fptr(d), prim.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(t)))
+        fn = lib().lr_selftest_brute if brute else lib().lr_selftest_intersect
+        _check(fn(self._h, n, _fptr(o), _fptr(d), prim.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(t)))
         return prim, t
+
+    def sky(self, dirs):
+        """sky.rs on the device: radiance seen along each unit direction, (n, 3)."""
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        if d.ndim != 2 or d.shape[1] != 3:
+            raise ValueError("dirs must be (n, 3)")
+        out = np.empty_like(d)
+        _check(lib().lr_selftest_sky(self._h, d.shape[0], _fptr(d), _fptr(out)))
+        return out
+
+    def emitter_pick(self, xi):
+        """objects.rs:37-51 on the device: emitter index chosen for each uniform draw."""
+        x = np.ascontiguousarray(xi, dtype=np.float32).reshape(-1)
+        k = np.empty(x.size, dtype=np.int32)
+        _check(lib().lr_selftest_emitter_pick(self._h, x.size, _fptr(x), k.ctypes.data_as(C.POINTER(C.c_int32))))
+        return k
 
 
 def selftest_math(fn, a, b=None, device=0):
@@ -141,6 +192,8 @@ def selftest_math(fn, a, b=None, device=0):
     bp = None
     if b is not None:
         b = np.ascontiguousarray(b, dtype=np.float32)
+        if b.shape != a.shape:
+            raise ValueError("selftest_math: a and b differ in shape")
         bp = _fptr(b)
     _check(lib().lr_selftest_math(device, fn, _fptr(a), bp, _fptr(out), a.size))
     return out
@@ -165,7 +218,7 @@ def selftest_rcp(lo_exp, hi_exp, device=0):
 
 
 def stats_dict(s):
-    d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests", "sky_fetches", "iterations")}
+    d = {k: int(getattr(s, k)) for k in ("samples", "segments", "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests", "sky_fetches", "iterations", "path_slots", "pipeline")}
     d["render_ms"] = float(s.render_ms)
     d["upload_ms"] = float(s.upload_ms)
     d["bvh_build_ms"] = float(s.bvh_build_ms)

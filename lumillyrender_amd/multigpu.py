@@ -36,7 +36,8 @@ def gather_film(film, dist=None, dst=0, group=None):
         return film
     import torch
     t = torch.from_numpy(film)
-    dist.reduce(t, dst=dst, group=group)
+    # `dst` is a rank of `group`; torch.distributed.reduce wants the global rank
+    dist.reduce(t, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
     return film
 
 
@@ -93,12 +94,18 @@ def gather_tiles(film, width, height, tile, dist=None, dst=0, group=None):
 class SharedFilm:
     """The film all ranks of one node render into.  `array` is an (H, W, 3) float32 view of a file in /dev/shm mapped by
     every rank; `collect()` makes the ranks' tiles visible on rank `dst` (a barrier).  Ranks on different hosts (or no
-    process group) get private arrays and `collect()` falls back to gather_tiles."""
+    process group) get private arrays and `collect()` falls back to gather_tiles.
+
+    Frame loop protocol: render -> collect() -> [dst reads the frame] -> release() -> next render.  `release()` is the
+    second barrier that keeps the other ranks from rendering frame k+1 into the film while dst still reads frame k; a
+    loop whose consumer only looks at the last frame (bench.py) may skip it.  The backing file is unlinked as soon as
+    every rank has mapped it, so a crashed job leaves nothing in /dev/shm."""
 
     def __init__(self, width, height, tile, dist=None, dst=0, group=None):
         import socket
         self.width, self.height, self.tile, self.dist, self.dst, self.group = width, height, tile, dist, dst, group
-        self.path = None
+        self.path = None                 # set only while the backing file still has a name (construction)
+        self.name = None                 # the name it had, for diagnostics
         self.shared = False
         active = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
         if active:
@@ -117,8 +124,13 @@ class SharedFilm:
             if rank != dst:
                 self.path = box[0]
                 self.array = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+            self.name = self.path
             self._owner = rank == dst
-            dist.barrier(group=group)
+            dist.barrier(group=group)                                 # every rank holds its mapping ...
+            if self._owner:
+                os.unlink(self.path)                                  # ... so the name can go: the pages live as long as the mappings
+            self.path = None
+            dist.barrier(group=group)                                 # nobody returns while the name still exists
         else:
             self.array = np.zeros((height, width, 3), dtype=np.float32)
             self._owner = False
@@ -131,12 +143,14 @@ class SharedFilm:
             gather_tiles(self.array, self.width, self.height, self.tile, self.dist, dst=self.dst, group=self.group)
         return self.array
 
+    def release(self):
+        """dst has consumed the frame: the ranks may render the next one into the film."""
+        if self.shared:
+            self.dist.barrier(group=self.group)
+
     def close(self):
         if self.shared:
             self.dist.barrier(group=self.group)
             arr, self.array = self.array, None
             del arr
-            if self._owner and self.path and os.path.exists(self.path):
-                os.unlink(self.path)
-            self.dist.barrier(group=self.group)                       # nobody returns before the file is gone
             self.shared = False

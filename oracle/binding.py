@@ -24,7 +24,8 @@ class LrOracleStats(C.Structure):
 
 
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_lib = None
+_FAST_PATH = os.path.join(_HERE, "liboracle_fast.so")      # same source, -O3 -mavx2 (the cpu_baseline build of BASELINE.md section 3)
+_libs = {}
 fp = C.POINTER(C.c_float)
 
 
@@ -32,13 +33,15 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+def lib(fast=False):
+    """fast=False: the parity build (-O2).  fast=True: the -O3 -mavx2 build timed as the CPU baseline; the two
+    must give identical bits (tests/test_oracle_properties.py checks it)."""
+    path = _FAST_PATH if fast else _LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         build()
-    l = C.CDLL(_LIB_PATH)
+    l = C.CDLL(path)
     l.lr_oracle_render.argtypes = [C.POINTER(abi.LrSceneDesc), C.POINTER(abi.LrRenderParams), C.POINTER(abi.LrTile), C.c_int,
                                    fp, C.c_size_t, C.c_int, C.c_int, C.c_float, C.POINTER(LrOracleStats)]
     l.lr_oracle_triangle_intersect.argtypes = [fp, fp, fp, C.c_int, fp]
@@ -72,6 +75,10 @@ def lib():
     l.lr_oracle_prim_sample.argtypes = [C.POINTER(abi.LrPrimitive), C.c_float, C.c_float, fp]
     l.lr_oracle_prim_sample.restype = None
     l.lr_oracle_intersect_batch.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, C.c_float, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    l.lr_oracle_sky_batch.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, fp]
+    l.lr_oracle_sky_batch.restype = None
+    l.lr_oracle_emitter_pick.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, C.POINTER(C.c_int32)]
+    l.lr_oracle_math_batch.argtypes = [C.c_int, fp, fp, fp, C.c_int]
     l.lr_oracle_sky_radiance.argtypes = [C.POINTER(abi.LrSceneDesc), fp, fp]
     l.lr_oracle_sky_radiance.restype = None
     for n in ("sin", "cos", "acos", "exp"):
@@ -80,7 +87,7 @@ def lib():
     for n in ("atan2", "pow", "fmod_pos"):
         f = getattr(l, "lr_oracle_" + n)
         f.argtypes, f.restype = [C.c_float, C.c_float], C.c_float
-    _lib = l
+    _libs[path] = l
     return l
 
 
@@ -88,10 +95,10 @@ def f3(v):
     return (C.c_float * len(v))(*[float(x) for x in v])
 
 
-BRUTE, BVH = 0, 1
+BRUTE, BVH, BVH_ORDERED = 0, 1, 2
 
 
-def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE, pad=0.0, with_stats=False):
+def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE, pad=0.0, with_stats=False, fast=False):
     """Render with the CPU oracle.  mode BRUTE = the closest-hit definition; BVH with pad == 0 is the
     reference's literal tree + candidate traversal (bvh.rs / aabb.rs)."""
     d = description.desc
@@ -102,7 +109,7 @@ def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE,
         n_tiles = 1
     img = np.zeros((h, w, 3), dtype=np.float32)
     st = LrOracleStats()
-    rc = lib().lr_oracle_render(description.desc_ptr, C.byref(params), tiles, n_tiles, img.ctypes.data_as(fp), w * 3,
+    rc = lib(fast).lr_oracle_render(description.desc_ptr, C.byref(params), tiles, n_tiles, img.ctypes.data_as(fp), w * 3,
                                 threads, mode, pad, C.byref(st))
     if rc != 0:
         raise RuntimeError(f"lr_oracle_render failed: {rc}")
@@ -120,6 +127,39 @@ def intersect(description, origins, dirs, mode=BRUTE, pad=0.0):
     if rc != 0:
         raise RuntimeError(f"lr_oracle_intersect_batch failed: {rc}")
     return prim, t
+
+
+def sky_batch(description, dirs):
+    d = np.ascontiguousarray(dirs, dtype=np.float32)
+    out = np.empty_like(d)
+    lib().lr_oracle_sky_batch(description.desc_ptr, d.shape[0], d.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    return out
+
+
+def emitter_pick(description, xi):
+    """objects.rs:37-51: (emitter index per draw, number of emitters)."""
+    x = np.ascontiguousarray(xi, dtype=np.float32).reshape(-1)
+    k = np.empty(x.size, dtype=np.int32)
+    n = lib().lr_oracle_emitter_pick(description.desc_ptr, x.size, x.ctypes.data_as(fp), k.ctypes.data_as(C.POINTER(C.c_int32)))
+    if n < 0:
+        raise RuntimeError("lr_oracle_emitter_pick failed")
+    return k, n
+
+
+_MATH_FN = {"sin": 0, "cos": 1, "acos": 2, "atan2": 3, "pow": 4, "exp": 5, "fmod_pos": 6}
+
+
+def math_batch(name, xs, ys=None):
+    """The oracle's deterministic math spec over whole arrays (one C call; for the exhaustive-ish sweeps)."""
+    a = np.ascontiguousarray(xs, dtype=np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if ys is not None:
+        b = np.ascontiguousarray(ys, dtype=np.float32)
+        bp = b.ctypes.data_as(fp)
+    rc = lib().lr_oracle_math_batch(_MATH_FN[name], a.ctypes.data_as(fp), bp, out.ctypes.data_as(fp), a.size)
+    assert rc == 0
+    return out
 
 
 def math1(name, xs):

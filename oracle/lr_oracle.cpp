@@ -689,6 +689,21 @@ struct BVH {
     nodes.clear(); nodes.reserve(prims.size() * 2);
     root = prims.empty() ? -1 : construct(leaf.data(), (int)leaf.size());
   }
+  // Slab test of aabb.rs:74-92 that also returns the clipped entry parameter (for mode 2's near-first order).
+  static bool aabb_entry(const AABB& a, const Ray& ray, const V3& inv_d, float pad, float* t_entry) {
+    float mn = -INF, mx = INF;
+    for (int i = 0; i < 3; ++i) {
+      float t1 = ((comp(a.mn, i) - pad) - comp(ray.origin, i)) * comp(inv_d, i);
+      float t2 = ((comp(a.mx, i) + pad) - comp(ray.origin, i)) * comp(inv_d, i);
+      float t_min, t_max;
+      if (t1 > t2) { t_min = t2; t_max = t1; } else { t_min = t1; t_max = t2; }
+      if (mn < t_min) mn = t_min;
+      if (mx > t_max) mx = t_max;
+      if (mn > mx) return false;
+    }
+    *t_entry = mn;
+    return true;
+  }
   void may_intersect(int ni, const Ray& ray, float pad, std::vector<int>& cand, uint64_t* visits) const {   // bvh.rs:20-25,38-45
     const BNode& b = nodes[ni];
     if (visits) ++*visits;
@@ -793,6 +808,40 @@ struct Scene {
         Intersection it;
         if (ct) ct->prim_tests++;
         if (prim_intersect(prims[i], ray, &it) && (!found || it.distance < best.distance)) { best = it; best.prim = (int)i; found = true; }
+      }
+    } else if (mode == 2) {
+      // "optimized" CPU baseline: the same tree, walked near child first with an explicit
+      // stack, subtrees entered beyond the best hit so far are skipped, no candidate vector.  Boxes only prune
+      // (pad > 0 keeps them conservative), ties go to the lowest primitive index: same result as mode 0.
+      int stack[128]; float stack_t[128]; int sp = 0;
+      V3 inv_d = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+      float te;
+      if (bvh.root >= 0 && BVH::aabb_entry(bvh.nodes[bvh.root].box, ray, inv_d, pad, &te)) { stack[sp] = bvh.root; stack_t[sp++] = te; }
+      if (ct && bvh.root >= 0) ct->node_visits++;
+      while (sp > 0) {
+        --sp;
+        int ni = stack[sp];
+        if (found && stack_t[sp] > best.distance + pad) continue;
+        const BNode& b = bvh.nodes[ni];
+        if (b.leaf_index >= 0) {
+          Intersection it; int i = b.leaf_index;
+          if (ct) ct->prim_tests++;
+          if (prim_intersect(prims[i], ray, &it)) {
+            bool better = !found || it.distance < best.distance || (it.distance == best.distance && i < best.prim);
+            if (better) { best = it; best.prim = i; found = true; }
+          }
+          continue;
+        }
+        float tl = 0.0f, tr = 0.0f;
+        bool hl = BVH::aabb_entry(bvh.nodes[b.left].box, ray, inv_d, pad, &tl);
+        bool hr = BVH::aabb_entry(bvh.nodes[b.right].box, ray, inv_d, pad, &tr);
+        if (ct) ct->node_visits += 2;
+        if (hl && hr) {
+          if (tl <= tr) { stack[sp] = b.right; stack_t[sp++] = tr; stack[sp] = b.left; stack_t[sp++] = tl; }
+          else { stack[sp] = b.left; stack_t[sp++] = tl; stack[sp] = b.right; stack_t[sp++] = tr; }
+        } else if (hl) { stack[sp] = b.left; stack_t[sp++] = tl; }
+        else if (hr) { stack[sp] = b.right; stack_t[sp++] = tr; }
+        if (sp > 120) return false;                                              // cannot happen for SAH trees of < 2^60 leaves
       }
     } else {
       std::vector<int> cand;
@@ -962,7 +1011,8 @@ struct LrOracleStats {
 };
 
 // mode 0: brute force; mode 1: reference SAH tree + collect-all traversal, boxes padded by `pad`
-// (pad = 0 is the literal reference).  n_threads <= 0 -> hardware_concurrency.
+// (pad = 0 is the literal reference); mode 2: the same tree walked near-first with early-out (the "optimized"
+// CPU baseline; needs pad > 0 to stay exact).  n_threads <= 0 -> hardware_concurrency.
 int lr_oracle_render(const LrSceneDesc* desc, const LrRenderParams* params, const LrTile* tiles, int n_tiles,
                      float* rgb_out, size_t row_stride_floats, int n_threads, int mode, float pad, LrOracleStats* stats) {
   if (!desc || !params || (!tiles && n_tiles > 0) || !rgb_out || params->spp <= 0) return LR_EINVAL;
@@ -1082,18 +1132,73 @@ void lr_oracle_prim_sample(const LrPrimitive* lp, float u, float v, float* out4)
 // closest hit over a batch of rays: out[i] = (prim index or -1, distance bits)
 int lr_oracle_intersect_batch(const LrSceneDesc* desc, int mode, float pad, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
   Scene s; if (!build_scene(desc, nullptr, mode, pad, &s)) return LR_EINVAL;
+  int n_threads = (int)std::thread::hardware_concurrency();
+  if (n_threads <= 0) n_threads = 1;
+  if (n < 4096) n_threads = 1;
+  std::atomic<int> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      int b = next.fetch_add(256);
+      if (b >= n) break;
+      int e = b + 256 < n ? b + 256 : n;
+      for (int i = b; i < e; ++i) {
+        Ray r; r.origin = arr3(origins + 3 * (size_t)i); r.direction = arr3(dirs + 3 * (size_t)i);
+        Intersection it;
+        if (s.intersect(r, &it, nullptr)) { prim_out[i] = it.prim; t_out[i] = it.distance; }
+        else { prim_out[i] = -1; t_out[i] = 0.0f; }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < n_threads; ++i) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+  return LR_OK;
+}
+// the deterministic math spec over arrays (fn numbering = the device's lr_selftest_math): 0 sin 1 cos 2 acos 3 atan2 4 pow 5 exp 6 fmod_pos
+int lr_oracle_math_batch(int fn, const float* a, const float* b, float* out, int n) {
   for (int i = 0; i < n; ++i) {
-    Ray r; r.origin = arr3(origins + 3 * i); r.direction = arr3(dirs + 3 * i);
-    Intersection it;
-    if (s.intersect(r, &it, nullptr)) { prim_out[i] = it.prim; t_out[i] = it.distance; }
-    else { prim_out[i] = -1; t_out[i] = 0.0f; }
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    switch (fn) {
+      case 0: r = det_sin(x); break;
+      case 1: r = det_cos(x); break;
+      case 2: r = det_acos(x); break;
+      case 3: r = det_atan2(x, y); break;
+      case 4: r = det_pow(x, y); break;
+      case 5: r = det_exp(x); break;
+      case 6: r = det_fmod_pos(x, y); break;
+      default: return LR_EINVAL;
+    }
+    out[i] = r;
   }
   return LR_OK;
+}
+// Objects::sample_emission's pick (objects.rs:37-51): k_out[i] = index into the emitter list for roulette = area * xi[i]
+int lr_oracle_emitter_pick(const LrSceneDesc* desc, int n, const float* xi, int32_t* k_out) {
+  Scene s; if (!build_scene(desc, nullptr, 0, 0.0f, &s)) return LR_EINVAL;
+  if (s.emission.empty()) return LR_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    float roulette = s.emission_area * xi[i];
+    float area = 0.0f; int pick = (int)s.emission.size() - 1;     // the reference's unreachable!() tail -> last emitter
+    for (size_t k = 0; k < s.emission.size(); ++k) {
+      area += s.prims[s.emission[k]].area;
+      if (roulette <= area) { pick = (int)k; break; }
+    }
+    k_out[i] = pick;
+  }
+  return (int)s.emission.size();
 }
 void lr_oracle_sky_radiance(const LrSceneDesc* desc, const float* dir, float* rgb) {
   Scene s; if (!build_scene(desc, nullptr, 0, 0.0f, &s)) { rgb[0] = rgb[1] = rgb[2] = 0; return; }
   Ray r; r.origin = v3(0, 0, 0); r.direction = arr3(dir);
   V3 c = s.sky_radiance(r, nullptr); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+void lr_oracle_sky_batch(const LrSceneDesc* desc, int n, const float* dirs, float* rgb) {
+  Scene s; if (!build_scene(desc, nullptr, 0, 0.0f, &s)) return;
+  for (int i = 0; i < n; ++i) {
+    Ray r; r.origin = v3(0, 0, 0); r.direction = arr3(dirs + 3 * (size_t)i);
+    V3 c = s.sky_radiance(r, nullptr); rgb[3 * (size_t)i] = c.x; rgb[3 * (size_t)i + 1] = c.y; rgb[3 * (size_t)i + 2] = c.z;
+  }
 }
 // math (compared with numpy in tests)
 float lr_oracle_sin(float x) { return det_sin(x); }

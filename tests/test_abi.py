@@ -30,6 +30,11 @@ def test_hip_library_exports_header_symbols():
     assert {"lr_scene_create", "lr_render", "lr_render_device", "lr_scene_destroy", "lr_get_stats", "lr_last_error", "lr_device_count"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n
+    diag = declared_functions("lumilly_hip_diag.h")          # diagnostics live in their own header, outside the drop-in surface
+    assert {"lr_selftest_math", "lr_selftest_intersect", "lr_selftest_brute", "lr_selftest_rng", "lr_selftest_rcp"} <= set(diag)
+    assert not (set(diag) & set(names)), "a diagnostic entry point leaked into the product header"
+    for n in diag:
+        assert hasattr(lib, n), n
     lib.lr_build_info.restype = C.c_char_p
     assert b"gfx950" in lib.lr_build_info()
 

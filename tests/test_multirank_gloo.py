@@ -72,17 +72,22 @@ def _shared_worker(rank, world, port, out_path):
     params = desc.render_params(spp=SPP, seed=4)
     film = multigpu.SharedFilm(W, H, TILE, dist, dst=0)
     assert film.shared
+    assert film.name and not os.path.exists(film.name)       # unlinked once every rank had mapped it: a crash leaks nothing
     tiles, n = multigpu.shard_tiles(W, H, TILE, rank, world)
-    img = oracle.render(desc, params, tiles, n, threads=1)
-    for i in range(n):                               # like lr_render: only the pixels of the tiles given
-        t = tiles[i]
-        film.array[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] = img[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w]
-    got = film.collect()
+    frames = []
+    for frame in range(2):                           # two frames through one film: collect / release keep them apart
+        p = desc.render_params(spp=SPP, seed=4 + frame)
+        img = oracle.render(desc, p, tiles, n, threads=1)
+        for i in range(n):                           # like lr_render: only the pixels of the tiles given
+            t = tiles[i]
+            film.array[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] = img[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w]
+        got = film.collect()
+        if rank == 0:
+            frames.append(np.array(got))             # dst consumes the frame ...
+        film.release()                               # ... before anybody renders the next one into the film
     if rank == 0:
-        np.save(out_path, np.array(got))
-    path = film.path
+        np.save(out_path, np.stack(frames))
     film.close()
-    assert not os.path.exists(path)
     dist.destroy_process_group()
 
 
@@ -95,5 +100,48 @@ def test_shared_memory_film(tmp_path, world):
     from oracle import binding as oracle
     desc = host.Description(scene_path("cbox-spheres.toml"))
     desc.set_resolution(W, H)
+    got = np.load(out_path)
+    for frame in range(2):
+        ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4 + frame), threads=2)
+        assert np.array_equal(got[frame], ref), frame
+
+
+def _subgroup_worker(rank, world, port, out_path):
+    """gather on a SUB-group whose dst is not global rank 0: `dst` is a rank of the group."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lumillyrender_amd import host, multigpu
+    from oracle import binding as oracle
+    grp = dist.new_group(ranks=[1, 2])
+    if rank in (1, 2):
+        desc = host.Description(scene_path("cbox-spheres.toml"))
+        desc.set_resolution(W, H)
+        params = desc.render_params(spp=SPP, seed=4)
+        g_rank, g_world = dist.get_rank(grp), dist.get_world_size(grp)
+        films = []
+        for fn in (multigpu.gather_film, None):
+            tiles, n = multigpu.shard_tiles(W, H, TILE, g_rank, g_world)
+            film = oracle.render(desc, params, tiles, n, threads=1)
+            if fn is not None:
+                fn(film, dist, dst=0, group=grp)
+            else:
+                multigpu.gather_tiles(film, W, H, TILE, dist, dst=0, group=grp)
+            films.append(film)
+        if g_rank == 0:
+            assert rank == 1
+            np.save(out_path, np.stack(films))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_on_a_subgroup(tmp_path):
+    out_path = str(tmp_path / "film.npy")
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), out_path), nprocs=3, join=True)
+    from lumillyrender_amd import host
+    from oracle import binding as oracle
+    desc = host.Description(scene_path("cbox-spheres.toml"))
+    desc.set_resolution(W, H)
     ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4), threads=2)
-    assert np.array_equal(np.load(out_path), ref)
+    got = np.load(out_path)
+    assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)

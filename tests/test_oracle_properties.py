@@ -9,7 +9,7 @@ import pytest
 
 from lumillyrender_amd import abi, host
 from oracle import binding as oracle
-from tests.conftest import scene_path
+from tests.conftest import ROOT, scene_path
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 f3 = oracle.f3
@@ -223,3 +223,47 @@ def test_fuzz_generator_scenes_load_and_render():
         assert img.shape == (12, 16, 3) and np.isfinite(img).all()
         seen.add((integ, cam))
     assert len(seen) >= 3
+
+
+# ---- round 2: the oracle's own variants agree with each other -----------------------------------------------
+
+def test_fast_build_and_ordered_traversal_give_the_same_bits():
+    """oracle/liboracle_fast.so (-O3 -mavx2, what bench.py times as cpu_baseline) and the -O2 parity build produce the
+    same film bit for bit, and the 'optimized' baseline mode (ordered early-out walk of the same tree) equals the
+    definition (brute force over all primitives)."""
+    from lumillyrender_amd import host
+    from oracle import binding as oracle
+    for name, w, h, spp in (("cbox-spheres.toml", 40, 32, 6), ("brdf-row.toml", 48, 27, 6), ("two-spheres.toml", 32, 32, 8)):
+        d = host.Description(os.path.join(ROOT, "scenes", name)); d.set_resolution(w, h)
+        p = d.render_params(spp=spp, seed=14)
+        brute = oracle.render(d, p, mode=oracle.BRUTE)
+        assert np.array_equal(brute, oracle.render(d, p, mode=oracle.BRUTE, fast=True)), name
+        assert np.array_equal(brute, oracle.render(d, p, mode=oracle.BVH, pad=0.05, fast=True)), name
+        assert np.array_equal(brute, oracle.render(d, p, mode=oracle.BVH_ORDERED, pad=0.05)), name
+        assert np.array_equal(brute, oracle.render(d, p, mode=oracle.BVH_ORDERED, pad=0.05, fast=True)), name
+
+
+def test_math_batch_equals_the_scalar_hooks():
+    from oracle import binding as oracle
+    rng = np.random.default_rng(4)
+    x = (rng.random(500) * 6.28).astype(np.float32)
+    assert np.array_equal(oracle.math_batch("sin", x), oracle.math1("sin", x))
+    assert np.array_equal(oracle.math_batch("cos", x), oracle.math1("cos", x))
+    u = (rng.random(500) * 2 - 1).astype(np.float32)
+    assert np.array_equal(oracle.math_batch("acos", u), oracle.math1("acos", u))
+    a, b = rng.standard_normal(500).astype(np.float32), rng.standard_normal(500).astype(np.float32)
+    assert np.array_equal(oracle.math_batch("atan2", a, b), oracle.math2("atan2", a, b))
+
+
+def test_threaded_intersect_batch_is_order_independent():
+    """lr_oracle_intersect_batch fans out over threads for large batches: same answers as small single-thread batches."""
+    from lumillyrender_amd import host
+    from oracle import binding as oracle
+    d = host.Description(os.path.join(ROOT, "scenes", "cbox-spheres.toml")); d.set_resolution(16, 16)
+    rng = np.random.default_rng(6)
+    o = (rng.random((6000, 3)) * 500).astype(np.float32)
+    v = rng.standard_normal((6000, 3)).astype(np.float32); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    p, t = oracle.intersect(d, o, v)
+    for lo in range(0, 6000, 1500):
+        q, s = oracle.intersect(d, o[lo:lo + 1500], v[lo:lo + 1500])
+        assert np.array_equal(p[lo:lo + 1500], q) and np.array_equal(t[lo:lo + 1500], s)
