@@ -1,8 +1,14 @@
 // lr_device.h -- HBM layouts shared by the kernels and the C ABI implementation.
 //
 // Scene blob (read-only, replicated per GPU; DESIGN.md "data layout in HBM"):
-//   nodes   8 x float4 per 4-wide BVH node (128 B, 112 used): {lo.x of child 0..3} {hi.x} {lo.y} {hi.y} {lo.z} {hi.z}
-//           {child 0..3 as int bits} {-}.  child >= 0 inner node, child < 0 leaf ~c = first<<3 | count,
+//   nodes   4 x float4 per 4-wide BVH node (64 B: two nodes per 128-B cache line), child boxes QUANTISED to 8 bits per
+//           plane on a power-of-two grid anchored at the node's lower corner:
+//             {origin.xyz, ex | ey << 8 | ez << 16}       e* = IEEE biased exponents of the grid steps 2^(e - 127)
+//             {qlo.x of child 0..3 (one byte each), qlo.y, qlo.z, qhi.x}
+//             {qhi.y, qhi.z, -, -}
+//             {child 0..3 as int bits}
+//           plane = origin + q * step; lower planes are rounded down, upper planes up, so a stored box contains the
+//           padded f32 box of the description.  child >= 0 inner node, child < 0 leaf ~c = first<<3 | count,
 //           0x7fffffff = empty slot.  lr_scene_create collapses the binary tree of the description (or of the device
 //           LBVH build) into this form: one fetch per two binary levels.
 //   prims   3 x float4 per primitive (48 B) IN LEAF ORDER, so a leaf reads consecutive rows:
@@ -31,6 +37,7 @@ namespace lr {
 
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr int kStackLdsMax = 25;       // traversal stack entries per lane kept in LDS by the streaming kernels (6 workgroups of 25 KB per CU)
+constexpr int kNodeRows = 4;         // float4 rows per 4-wide node (64 B)
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
 constexpr int kFlatMax = 32;          // scenes up to this many primitives skip the tree
@@ -61,6 +68,7 @@ struct DevScene {
   // worst case of a 4-wide tree (3 pushes per level) would otherwise cap a CU at 3 workgroups.  Set per launch.
   int   stack_lds, spill_depth;
   uint32_t* stack_spill;
+  float key_lo[3], key_scale[3];       // ray sort: cell = (origin - key_lo) * key_scale, 4 cells per axis over the scene's bounding box
   int   n_emitters;
   float emission_area;
   int   sky_type;
@@ -82,6 +90,8 @@ struct DevState {
   uint32_t* c_shade;                   // [queue][segment] counts
   uint32_t* q_shadow;                  // [bsdf][segment][kSeg] slot ids with a pending shadow ray, written by k_shade<bsdf>
   uint32_t* c_shadow;                  // [bsdf][segment] counts
+  uint16_t* sort_key;                  // [slot] scratch of the ray sort (k_trace / k_shadow): the bin of the i-th entry of a range
+  uint16_t* order;                     // [slot] sorted order of a range's rays as local slot numbers (< 16384); null = no sort
   uint4*    pool;                      // per-segment work-item pool {r0 next, r0 end, r1 next, r1 end}
   uint32_t* next_item;                 // global work-item dispenser
   uint32_t* n_retired;                 // slots that found pool and dispenser empty
@@ -100,6 +110,7 @@ struct DevState {
   // finish pass: 128 / 256 instead of 24 / 64 tripled such scenes.  Small jobs keep small batches (tail balance).
   uint32_t pool_low, pool_batch;
   uint32_t trace_spb;                  // segments per k_trace workgroup pass: its per-BSDF lists span that many segments
+  uint32_t shade_ordered;              // k_shade turns each list back into slot order in LDS before shading (coalesced state rows)
   int stack_depth;                     // LDS traversal stack entries per lane
 };
 

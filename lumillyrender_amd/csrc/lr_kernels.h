@@ -146,10 +146,12 @@ LR_DEV bool trav_pop(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n)
   return false;
 }
 
-// One inner node (s.cur >= 0) of the 4-wide tree: one 112-B fetch tests four child boxes, the hit children are
+// One inner node (s.cur >= 0) of the 4-wide tree: one 64-B fetch tests four child boxes, the hit children are
 // ordered by entry distance (5-comparator network), the nearest becomes the next node and the others go on the
 // stack far-first.  Half the dependent fetch rounds of a binary tree -- the traversal is latency-bound, not
-// bandwidth-bound.  false = ray finished.
+// bandwidth-bound.  The boxes are 8-bit planes on the node's own power-of-two grid
+// (lr_device.h); instead of decoding them to world space the RAY is moved into the grid: per axis
+// t(q) = q * (step * 1/d) + (origin - o) * 1/d, one conversion and one FMA per plane.  false = ray finished.
 constexpr int kEmptyChild = 0x7fffffff;
 LR_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
   bool sw = kb < ka;
@@ -157,26 +159,37 @@ LR_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
   int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
   ka = k0; kb = k1; ra = r0; rb = r1;
 }
+LR_DEV float qbyte(uint32_t w, int k) {                                  // byte k of w as a float (v_cvt_f32_ubyte0..3)
+  return (float)((w >> (8 * k)) & 0xffu);
+}
 template <bool SHADOW>
 LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
-  const float4* n = sc.nodes + 8 * (size_t)s.cur;
-  float4 lox = n[0], hix = n[1], loy = n[2], hiy = n[3], loz = n[4], hiz = n[5], rc = n[6];
+  const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
+  float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
   s.visits += 4;
   float k0, k1, k2, k3;
   int r0 = __float_as_int(rc.x), r1 = __float_as_int(rc.y), r2 = __float_as_int(rc.z), r3 = __float_as_int(rc.w);
   {
 #pragma clang fp contract(fast)
     const float inf = __builtin_inff();
+    const uint32_t eb = __float_as_uint(g.w);
+    // step * 1/d is exact (a power of two times a float); the offset costs two roundings of magnitude |o| ulp, far inside
+    // the padding the boxes carry
+    const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = __builtin_fmaf(g.x, s.ix, s.ox);
+    const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = __builtin_fmaf(g.y, s.iy, s.oy);
+    const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = __builtin_fmaf(g.z, s.iz, s.oz);
+    const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
+    const uint32_t hx = __float_as_uint(qa.w), hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
 #define LR_SLAB(K, C, R)                                                                                         \
     {                                                                                                            \
-      float a0 = __builtin_fmaf(lox.C, s.ix, s.ox), a1 = __builtin_fmaf(hix.C, s.ix, s.ox);                      \
-      float b0 = __builtin_fmaf(loy.C, s.iy, s.oy), b1 = __builtin_fmaf(hiy.C, s.iy, s.oy);                      \
-      float c0 = __builtin_fmaf(loz.C, s.iz, s.oz), c1 = __builtin_fmaf(hiz.C, s.iz, s.oz);                      \
+      float a0 = __builtin_fmaf(qbyte(lx, C), ax, bx), a1 = __builtin_fmaf(qbyte(hx, C), ax, bx);                \
+      float b0 = __builtin_fmaf(qbyte(ly, C), ay, by), b1 = __builtin_fmaf(qbyte(hy, C), ay, by);                \
+      float c0 = __builtin_fmaf(qbyte(lz, C), az, bz), c1 = __builtin_fmaf(qbyte(hz, C), az, bz);                \
       float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f)); \
       float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull)); \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
-    LR_SLAB(k0, x, r0) LR_SLAB(k1, y, r1) LR_SLAB(k2, z, r2) LR_SLAB(k3, w, r3)
+    LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)
 #undef LR_SLAB
     int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
     if (n_hit == 0) return trav_pop<SHADOW>(sc, s, stk_n);
@@ -802,6 +815,82 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Ray sort (north star: "ray sort/compaction").  Before a workgroup walks the rays of its range (up to 16 K path slots)
+// it bins them by (direction octant, 4x4x4 cell of the origin in Morton order): a 9-bit counting sort through an LDS
+// histogram, the sorted order left as 16-bit local slot numbers in `order`.  Waves then draw 64 consecutive entries of
+// that order at a time, so the lanes of a wave start next to each other, leave in the same octant, descend the same
+// top of the tree (same cache lines, same near-first child order) and stay in step between node and leaf phases.
+// The order only changes WHICH lane walks WHICH ray: hits, lists and films are the same bits.
+// ------------------------------------------------------------------------------------------
+constexpr int kSortBins = 512;
+constexpr uint32_t kDeadKey = 0xffffu;
+struct SortLds { uint32_t hist[kSortBins]; uint32_t wsum[kBlock / 64]; };
+
+LR_DEV uint32_t ray_key(const DevScene& sc, V3 o, V3 d) {
+  uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+  float fx = (o.x - sc.key_lo[0]) * sc.key_scale[0], fy = (o.y - sc.key_lo[1]) * sc.key_scale[1], fz = (o.z - sc.key_lo[2]) * sc.key_scale[2];
+  uint32_t cx = (uint32_t)__builtin_fminf(__builtin_fmaxf(fx, 0.0f), 3.0f);      // fmax(NaN, 0) = 0: any ray gets a valid bin
+  uint32_t cy = (uint32_t)__builtin_fminf(__builtin_fmaxf(fy, 0.0f), 3.0f);
+  uint32_t cz = (uint32_t)__builtin_fminf(__builtin_fmaxf(fz, 0.0f), 3.0f);
+  uint32_t m = (cx & 1u) | ((cy & 1u) << 1) | ((cz & 1u) << 2) | ((cx & 2u) << 2) | ((cy & 2u) << 3) | ((cz & 2u) << 4);
+  return (oct << 6) | m;
+}
+// histogram -> exclusive offsets, in place (call with the whole workgroup, between barriers); returns the number of keys
+LR_DEV uint32_t sort_scan(SortLds& sl) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t a = sl.hist[2 * tid], b = sl.hist[2 * tid + 1];
+  uint32_t v = a + b;
+  for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if ((int)lane >= off) v += t; }
+  if (lane == 63u) sl.wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0, all = 0;
+  for (uint32_t w = 0; w < kBlock / 64; ++w) { uint32_t x = sl.wsum[w]; all += x; if (w < wave) pre += x; }
+  uint32_t excl = pre + v - (a + b);
+  sl.hist[2 * tid] = excl; sl.hist[2 * tid + 1] = excl + a;
+  __syncthreads();
+  return all;
+}
+static_assert(kSortBins == 2 * kBlock, "sort_scan gives two bins to each thread");
+
+// A wave's window on the sorted order: 64 entries at a time (one per lane in `cv`), the next 64 requested one draw
+// ahead (`nv`) so that a refill never waits for the order list.  pos / len / nlen are wave-uniform.  Written as a macro
+// pair over plain locals: as a struct passed by reference the compiler kept the window in scratch memory and waited
+// for the prefetch right behind its issue.
+#define LR_CHUNK_DECL uint32_t ck_cv = 0, ck_nv = 0, ck_pos = 0, ck_len = 0, ck_nlen = 0;
+// request the next 64 entries (no-op once the range's dispenser has run dry: ck_nlen stays 0)
+#define LR_CHUNK_FETCH(S_NEXT, ORD, N_LIVE)                                                             \
+  {                                                                                                     \
+    uint32_t base_ = 0;                                                                                 \
+    if (lane_id() == 0) base_ = atomicAdd(S_NEXT, 64u);                                                 \
+    base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_);                                       \
+    ck_nlen = base_ < (N_LIVE) ? ((N_LIVE) - base_ < 64u ? (N_LIVE) - base_ : 64u) : 0u;               \
+    ck_nv = lane_id() < ck_nlen ? (uint32_t)(ORD)[base_ + lane_id()] : 0u;                              \
+  }
+// Hands entries of the sorted order to the lanes with NEED set: GOT = this lane received one (its local slot number in
+// LOCAL), EXHAUSTED = nothing is left for this wave to draw.  Whole (converged) wave.
+#define LR_CHUNK_TAKE(S_NEXT, ORD, N_LIVE, NEED, GOT, LOCAL, EXHAUSTED)                                 \
+  {                                                                                                     \
+    bool need_ = (NEED);                                                                                \
+    uint64_t nm_ = __ballot(need_);                                                                     \
+    while (nm_ != 0) {                                                                                  \
+      if (ck_pos == ck_len) {                                                                           \
+        if (ck_nlen == 0) break;                                                                        \
+        ck_cv = ck_nv; ck_len = ck_nlen; ck_pos = 0;                                                    \
+        LR_CHUNK_FETCH(S_NEXT, ORD, N_LIVE)                                                             \
+      }                                                                                                 \
+      const uint32_t avail_ = ck_len - ck_pos;                                                          \
+      const uint32_t r_ = rank_in_mask(nm_);                                                            \
+      const bool take_ = need_ && r_ < avail_;                                                          \
+      const uint32_t v_ = (uint32_t)__shfl((int)ck_cv, (int)(take_ ? ck_pos + r_ : 0u), 64);            \
+      if (take_) { LOCAL = v_; GOT = true; need_ = false; }                                             \
+      const uint32_t cnt_ = (uint32_t)__builtin_popcountll(nm_);                                        \
+      ck_pos += cnt_ < avail_ ? cnt_ : avail_;                                                          \
+      nm_ = __ballot(need_);                                                                            \
+    }                                                                                                   \
+    EXHAUSTED = ck_pos == ck_len && ck_nlen == 0;                                                       \
+  }
+
 // Closest-hit stage of the streaming pipeline.  A workgroup owns `spb` consecutive segments (spb * 512
 // path slots) per pass and hands them to its waves through an LDS dispenser:
 //   * tree scenes: persistent while-while traversal with DYNAMIC RAY FETCH -- a lane whose ray is done
@@ -819,12 +908,13 @@ constexpr int kMaxGroup = 32;            // segments a workgroup may own at once
 #endif
 constexpr int kRefillBelow = LR_REFILL_BELOW;         // refill the wave when at most this many lanes are still traversing
 
-template <bool COUNT>
+template <bool COUNT, bool SORTED>
 __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, DevState st, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_cnt[8];                                    // one list per BSDF for the whole range of this pass (k_shade cuts it into 512-entry slices)
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
+  SortLds& s_sort = *(SortLds*)lds;                                 // the histogram borrows the traversal stack's LDS: the sort runs before any ray walks
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
@@ -860,6 +950,34 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
         }
       }
     } else {
+      // ---- ray sort: bin the range's live rays, leave the sorted order in st.order[slot0 ...] ----
+      constexpr bool sorted = SORTED;
+      uint32_t n_live = total;
+      if (sorted) {
+        for (uint32_t b = tid; b < (uint32_t)kSortBins; b += kBlock) s_sort.hist[b] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += kBlock) {
+          float4 ro = st.ray_o[slot0 + i];
+          uint32_t key = kDeadKey;
+          if (__float_as_int(ro.w) >= 0) {
+            float4 rd = st.ray_d[slot0 + i];
+            key = ray_key(sc, v3(ro), v3(rd));
+            atomicAdd(&s_sort.hist[key], 1u);
+          }
+          st.sort_key[slot0 + i] = (uint16_t)key;
+        }
+        __syncthreads();
+        n_live = sort_scan(s_sort);
+        for (uint32_t i = tid; i < total; i += kBlock) {
+          uint32_t key = st.sort_key[slot0 + i];                    // this thread's own store
+          if (key != kDeadKey) { uint32_t pos = atomicAdd(&s_sort.hist[key], 1u); st.order[slot0 + pos] = (uint16_t)i; }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      const uint16_t* ord = sorted ? st.order + slot0 : nullptr;
+      LR_CHUNK_DECL
+      if (sorted) LR_CHUNK_FETCH(&s_next, ord, n_live)
       Trav<false> tr;
       bool has = false, fin = false;
       uint32_t slot = 0;
@@ -884,17 +1002,29 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           }
           if (f) { has = false; fin = false; }
         }
-        // ---- dynamic fetch: free lanes draw the next slots of this workgroup's range ----
+        // ---- dynamic fetch: free lanes draw the next rays of this workgroup's range ----
         bool need = !has;
-        uint32_t idx = wave_reserve(&s_next, need);
-        bool exhausted = __ballot(need && idx >= total) != 0;       // the dispenser is monotonic: one lane past the end = empty for all
-        if (need && idx < total) {
-          slot = slot0 + idx;
-          float4 ro = st.ray_o[slot];
-          if (__float_as_int(ro.w) >= 0) {
-            float4 rd = st.ray_d[slot];
+        bool exhausted;
+        if (sorted) {
+          uint32_t local = 0; bool got = false;
+          LR_CHUNK_TAKE(&s_next, ord, n_live, need, got, local, exhausted)
+          if (got) {
+            slot = slot0 + local;
+            float4 ro = st.ray_o[slot], rd = st.ray_d[slot];         // every entry of the order is a live ray
             trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
             has = true; n_rays += 1;
+          }
+        } else {
+          uint32_t idx = wave_reserve(&s_next, need);
+          exhausted = __ballot(need && idx >= total) != 0;           // the dispenser is monotonic: one lane past the end = empty for all
+          if (need && idx < total) {
+            slot = slot0 + idx;
+            float4 ro = st.ray_o[slot];
+            if (__float_as_int(ro.w) >= 0) {
+              float4 rd = st.ray_d[slot];
+              trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
+              has = true; n_rays += 1;
+            }
           }
         }
         if (__ballot(has) == 0) { if (exhausted) break; continue; }
@@ -1011,11 +1141,22 @@ LR_DEV void shadow_resolve(const DevScene& sc, const DevState& st, uint32_t slot
   }
 }
 
+// Slot-ordered shading.  k_trace appends a slot to its BSDF's list when the ray retires, i.e. in traversal-completion
+// order (and, with the ray sort, in sorted-ray order): shading in that order reads and writes the 16-B state rows of
+// scattered slots, eight unrelated wave-instructions per 128-B line.  The prologue below turns the list back into slot
+// order -- a bitmap of the range's slots in LDS (one atomic OR per entry), then every thread writes the set bits of its
+// two words into an LDS list behind a workgroup prefix sum -- so that 64 lanes shade (nearly) consecutive slots.
+constexpr int kRangeSlots = kMaxGroup * kSeg;                       // 16384: slots of the largest range
+struct ShadeOrderLds { uint32_t bits[kRangeSlots / 32]; uint32_t wsum[kBlock / 64]; uint16_t list[kRangeSlots]; };
+static_assert(kRangeSlots / 32 == 2 * kBlock, "two bitmap words per thread");
+
 template <int MT>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevParams rp) {
+  extern __shared__ uint32_t shade_lds[];                           // ShadeOrderLds when st.shade_ordered, else nothing
   __shared__ PoolLds pl;
   __shared__ uint32_t s_shadow, s_retired;
   __shared__ uint32_t s_stat[ST_COUNT];
+  ShadeOrderLds& so = *(ShadeOrderLds*)shade_lds;
   if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
   // k_trace left ONE list per BSDF for each range of trace_spb segments (contiguous storage).  A workgroup shades a
@@ -1031,11 +1172,29 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
     // that still runs short falls back to the global dispenser (finish_and_regenerate), it never loses work
     const uint32_t batch = n / 4 < (uint32_t)kSeg ? (uint32_t)kSeg : (n / 4 > 8192u ? 8192u : n / 4);
     if (threadIdx.x == 0) { pool_begin(st, g0, n < batch ? n : batch, &pl, false, batch); s_shadow = 0; s_retired = 0; }
+    const bool ordered = st.shade_ordered != 0;
+    const uint32_t slot0 = g0 * kSeg;
+    if (ordered) {
+      const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+      so.bits[2 * tid] = 0; so.bits[2 * tid + 1] = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < n; i += kBlock) { uint32_t l = queue[i] - slot0; atomicOr(&so.bits[l >> 5], 1u << (l & 31u)); }
+      __syncthreads();
+      uint32_t w0 = so.bits[2 * tid], w1 = so.bits[2 * tid + 1];
+      uint32_t c = (uint32_t)__builtin_popcount(w0) + (uint32_t)__builtin_popcount(w1), v = c;
+      for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if ((int)lane >= off) v += t; }
+      if (lane == 63u) so.wsum[wave] = v;
+      __syncthreads();
+      uint32_t pre = v - c;
+      for (uint32_t w = 0; w < wave; ++w) pre += so.wsum[w];
+      while (w0) { uint32_t b = (uint32_t)__builtin_ctz(w0); w0 &= w0 - 1; so.list[pre++] = (uint16_t)(64u * tid + b); }
+      while (w1) { uint32_t b = (uint32_t)__builtin_ctz(w1); w1 &= w1 - 1; so.list[pre++] = (uint16_t)(64u * tid + 32u + b); }
+    }
     __syncthreads();
     for (uint32_t base = 0; base < n; base += kBlock) {
       uint32_t i = base + threadIdx.x;
       bool valid = i < n;
-      uint32_t slot = valid ? queue[i] : 0;
+      uint32_t slot = valid ? (ordered ? slot0 + so.list[i] : queue[i]) : 0;
       VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
       float4 acc_row = st.acc[slot];                                // every wave finishes some path: fetch the chunk sum with the rest of the state
       if (valid) v = shade_vertex<MT>(sc, st, rp, slot);
@@ -1065,12 +1224,13 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 // Shadow stage of the streaming pipeline (scene.rs:127-147).  mt_mask = BSDF types present in the scene
 // (their k_shade wrote this iteration's shadow lists).  Same workgroup ranges and the same dynamic ray
 // fetch as k_trace; the work list is the concatenation of the range's per-BSDF shadow lists.
-template <bool COUNT>
+template <bool COUNT, bool SORTED>
 __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_pref[8];                                    // prefix over the range's per-BSDF shadow lists (k_shade writes one per range)
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_stat[ST_COUNT];
+  SortLds& s_sort = *(SortLds*)lds;                                 // borrows the traversal stack's LDS (see k_trace)
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   if (tid < ST_COUNT) s_stat[tid] = 0;
@@ -1088,6 +1248,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, 
     }
     __syncthreads();
     const uint32_t total = s_pref[kNumShadeQueues - 1];
+    const uint32_t slot0 = seg0 * kSeg;
     const uint32_t p1 = s_pref[1], p2 = s_pref[2], p3 = s_pref[3], p4 = s_pref[4];
     auto entry_slot = [&](uint32_t i) -> uint32_t {                 // i-th shadow ray of the range -> slot id
       uint32_t k = (i >= p1 ? 1u : 0u) + (i >= p2 ? 1u : 0u) + (i >= p3 ? 1u : 0u) + (i >= p4 ? 1u : 0u);
@@ -1105,6 +1266,33 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, 
         shadow_resolve(sc, st, slot, o, dir, r);
       }
     } else {
+      // ---- ray sort over the range's shadow entries (origin = the path vertex, direction = towards the sampled light point) ----
+      constexpr bool sorted = SORTED;
+      uint32_t n_live = total;
+      if (sorted) {
+        for (uint32_t b = tid; b < (uint32_t)kSortBins; b += kBlock) s_sort.hist[b] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += kBlock) {
+          uint32_t sl = entry_slot(i);
+          float4 ro = st.ray_o[sl], sd = st.sh_d[sl];
+          uint32_t key = ray_key(sc, v3(ro), v3(sd));
+          atomicAdd(&s_sort.hist[key], 1u);
+          st.sort_key[slot0 + i] = (uint16_t)key;
+        }
+        __syncthreads();
+        n_live = sort_scan(s_sort);
+        for (uint32_t i = tid; i < total; i += kBlock) {
+          uint32_t sl = entry_slot(i);
+          uint32_t key = st.sort_key[slot0 + i];                    // this thread's own store
+          uint32_t pos = atomicAdd(&s_sort.hist[key], 1u);
+          st.order[slot0 + pos] = (uint16_t)(sl - slot0);
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      const uint16_t* ord = sorted ? st.order + slot0 : nullptr;
+      LR_CHUNK_DECL
+      if (sorted) LR_CHUNK_FETCH(&s_next, ord, n_live)
       Trav<true> tr;
       bool has = false, fin = false;
       uint32_t slot = 0;
@@ -1116,10 +1304,18 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, 
           has = false; fin = false;
         }
         bool need = !has;
-        uint32_t idx = wave_reserve(&s_next, need);
-        bool exhausted = __ballot(need && idx >= total) != 0;
-        if (need && idx < total) {
-          slot = entry_slot(idx);
+        bool exhausted, drew = false;
+        if (sorted) {
+          uint32_t local = 0;
+          LR_CHUNK_TAKE(&s_next, ord, n_live, need, drew, local, exhausted)
+          if (drew) slot = slot0 + local;
+        } else {
+          uint32_t idx = wave_reserve(&s_next, need);
+          exhausted = __ballot(need && idx >= total) != 0;
+          drew = need && idx < total;
+          if (drew) slot = entry_slot(idx);
+        }
+        if (drew) {
           float4 ro = st.ray_o[slot], sd = st.sh_d[slot];
           trav_begin<true>(tr, v3(ro), v3(sd), sd.w);
           has = true; n_q += 1;

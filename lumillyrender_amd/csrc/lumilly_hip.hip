@@ -87,6 +87,7 @@ struct LrScene {
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
   DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill;
+  DevBuf<uint16_t> sort_key, order;
   DevBuf<uint4> pool;
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
@@ -107,6 +108,12 @@ namespace {
 // lr_device.h.  A node adopts its grandchildren: starting from its two children, the inner child with the largest
 // surface area is replaced by its own two children until four slots are filled.  Leaves keep their encoding.
 // Returns the worst-case traversal stack need (sum over a root-to-leaf path of children - 1).
+//
+// The child boxes are stored QUANTISED (lr_device.h: 64-B node): 8 bits per plane on a power-of-two grid anchored at
+// the node's lower corner, lower planes rounded down and upper planes rounded up, so a stored box always CONTAINS the
+// (already padded) box it came from.  Boxes only prune -- the closest hit is defined by the primitive tests alone
+// (aabb.rs:74-92 decides nothing a primitive test would accept differently) -- so the quantisation changes how many
+// nodes a ray visits, never a result.
 struct Wide4Builder {
   const std::vector<float4>& in;
   std::vector<float4>& out;
@@ -121,8 +128,8 @@ struct Wide4Builder {
     two[1] = Cand{{x.z, y.z, z.z}, {x.w, y.w, z.w}, __builtin_bit_cast(int, c.y)};
   }
   int build(int node, int* need_out) {
-    const size_t me = out.size() / 8;
-    out.resize(out.size() + 8, make_float4(0, 0, 0, 0));
+    const size_t me = out.size() / kNodeRows;
+    out.resize(out.size() + kNodeRows, make_float4(0, 0, 0, 0));
     Cand c[4]; int n = 2;
     children(node, c);
     while (n < 4) {
@@ -133,7 +140,7 @@ struct Wide4Builder {
       c[pick] = two[0]; c[n++] = two[1];
     }
     int need = 0;
-    float rows[7][4];
+    int refs[4];
     for (int k = 0; k < 4; ++k) {
       int ref = kEmptyChild;
       if (k < n) {
@@ -141,10 +148,42 @@ struct Wide4Builder {
         if (ref >= 0) { int sub = 0; ref = build(ref, &sub); need = std::max(need, n - 1 + sub); }
         else need = std::max(need, n - 1);
       }
-      for (int a = 0; a < 3; ++a) { rows[2 * a][k] = k < n ? c[k].lo[a] : 0.0f; rows[2 * a + 1][k] = k < n ? c[k].hi[a] : 0.0f; }
-      rows[6][k] = __builtin_bit_cast(float, ref);
+      refs[k] = ref;
     }
-    for (int r = 0; r < 7; ++r) out[me * 8 + r] = make_float4(rows[r][0], rows[r][1], rows[r][2], rows[r][3]);
+    // grid: origin = the lower corner of the union (an f32), step 2^e per axis with 255 steps covering the extent
+    float org[3]; uint32_t ebits = 0; uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+      float lo = c[0].lo[a], hi = c[0].hi[a];
+      for (int k = 1; k < n; ++k) { lo = std::fmin(lo, c[k].lo[a]); hi = std::fmax(hi, c[k].hi[a]); }
+      if (!(std::fabs(lo) < INFINITY) || !(std::fabs(hi) < INFINITY) || hi < lo) fail(LR_EINVAL, "BVH box is not finite");
+      org[a] = lo;
+      const double ext = (double)hi - (double)lo;
+      int e = -126;
+      if (ext > 0.0) { int ex; (void)std::frexp(ext / 255.0, &ex); e = ex; }          // 2^ex > ext / 255 >= 2^(ex-1)
+      if (e > 40) fail(LR_EUNSUPPORTED, "scene extent beyond 2^48: outside the range the traversal arithmetic keeps finite");
+      e = std::max(-126, e);
+      const double step = std::ldexp(1.0, e);
+      if (255.0 * step < ext) fail(LR_EUNSUPPORTED, "BVH box extent outside the quantisation range");
+      ebits |= (uint32_t)(e + 127) << (8 * a);
+      for (int k = 0; k < 4; ++k) {
+        uint32_t ql = 255, qh = 0;                                                     // empty slot: inverted (also skipped by its child reference)
+        if (k < n) {
+          double fl = std::floor(((double)c[k].lo[a] - (double)lo) / step), ce = std::ceil(((double)c[k].hi[a] - (double)lo) / step);
+          fl = std::max(0.0, std::min(255.0, fl)); ce = std::max(0.0, std::min(255.0, ce));
+          // decoded planes are exact in double (f32 origin + an integer multiple of a power of two): make sure they contain
+          while (fl > 0.0 && (double)lo + fl * step > (double)c[k].lo[a]) fl -= 1.0;
+          while (ce < 255.0 && (double)lo + ce * step < (double)c[k].hi[a]) ce += 1.0;
+          if ((double)lo + fl * step > (double)c[k].lo[a] || (double)lo + ce * step < (double)c[k].hi[a]) fail(LR_EUNSUPPORTED, "BVH box cannot be quantised conservatively");
+          ql = (uint32_t)fl; qh = (uint32_t)ce;
+        }
+        qlo[a] |= ql << (8 * k); qhi[a] |= qh << (8 * k);
+      }
+    }
+    auto fb = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    out[me * kNodeRows + 0] = make_float4(org[0], org[1], org[2], fb(ebits));
+    out[me * kNodeRows + 1] = make_float4(fb(qlo[0]), fb(qlo[1]), fb(qlo[2]), fb(qhi[0]));
+    out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), 0.0f, 0.0f);
+    out[me * kNodeRows + 3] = make_float4(fb((uint32_t)refs[0]), fb((uint32_t)refs[1]), fb((uint32_t)refs[2]), fb((uint32_t)refs[3]));
     *need_out = need;
     return (int)me;
   }
@@ -324,7 +363,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     Wide4Builder{nodes, wide}.build(0, &need);
     if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
     s.stack_depth = need + 1;
-    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes, stack need %d\n", nodes.size() / 4, wide.size() / 8, need);
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d\n", nodes.size() / 4, wide.size() / kNodeRows, kNodeRows * 16, need);
     s.nodes.upload(wide, s.stream);
     if (!built_on_device) s.prims.upload(prims, s.stream);
   }
@@ -373,6 +412,21 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
   s.film_w = c.resolution[0]; s.film_h = c.resolution[1];
   s.n_prims = np;
+  {
+    // bounding box of the primitives for the ray sort's 4x4x4 origin cells (only groups rays; never decides anything)
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = 0; i < np; ++i) {
+      const LrPrimitive& p = d.prims[i];
+      const int nv = p.type == LR_PRIM_TRIANGLE ? 3 : 1;
+      const float r = p.type == LR_PRIM_TRIANGLE ? 0.0f : std::fabs(p.v[3]);
+      for (int k = 0; k < nv; ++k) for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p.v[3 * k + a] - r); hi[a] = std::fmax(hi[a], p.v[3 * k + a] + r); }
+    }
+    for (int a = 0; a < 3; ++a) {
+      float ext = hi[a] - lo[a];
+      v.key_lo[a] = np > 0 ? lo[a] : 0.0f;
+      v.key_scale[a] = (np > 0 && ext > 0.0f && ext < 3.0e38f) ? 4.0f / ext : 0.0f;
+    }
+  }
 }
 
 int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
@@ -473,6 +527,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.q_shade.ensure((size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
   s.q_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
   s.pool.ensure(n_seg);
+  const bool sort_rays = !resident && s.dev.n_flat == 0 && !(std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 0);
+  if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
   s.counters.ensure(4);
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 8);
   s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
@@ -491,6 +547,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.ray_o = s.ray_o.p; ds.ray_d = s.ray_d.p; ds.hit = s.hit.p; ds.thr = s.thr.p; ds.rad = s.rad.p; ds.acc = s.acc.p;
   ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p;
   ds.q_shade = s.q_shade.p; ds.c_shade = s.c_shade.p; ds.q_shadow = s.q_shadow.p; ds.c_shadow = s.c_shadow.p; ds.pool = s.pool.p;
+  ds.sort_key = sort_rays ? s.sort_key.p : nullptr; ds.order = sort_rays ? s.order.p : nullptr;
+  const bool shade_ordered = !resident && !(std::getenv("LR_SHADE_ORDER") && std::atoi(std::getenv("LR_SHADE_ORDER")) == 0);
+  ds.shade_ordered = shade_ordered ? 1u : 0u;
+  const size_t shade_lds = shade_ordered ? sizeof(ShadeOrderLds) : 0;
   ds.next_item = s.counters.p; ds.n_retired = s.counters.p + 1;
   if (want_packed) s.packed.ensure((size_t)std::max<uint32_t>(n_pix, 1) * 3);
   ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p; ds.packed = want_packed ? s.packed.p : nullptr;
@@ -517,9 +577,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (6 workgroups of 25 KB per CU, the
   // occupancy their 80 VGPRs allow), the rest of the worst case in a spill buffer that near-first traversal rarely reaches
   const int stack_in_lds = resident ? s.stack_depth : std::min(s.stack_depth, stack_lds_limit());
-  const size_t lds = (size_t)stack_in_lds * kBlock * 4;
-  const void* ktrace = count ? (const void*)k_trace<true> : (const void*)k_trace<false>;
-  const void* kshadow = count ? (const void*)k_shadow<true> : (const void*)k_shadow<false>;
+  const size_t lds = std::max((size_t)stack_in_lds * kBlock * 4, sort_rays ? sizeof(SortLds) : (size_t)0);   // the sort's histogram borrows the stack
+  const void* ktrace = count ? (sort_rays ? (const void*)k_trace<true, true> : (const void*)k_trace<true, false>) : (sort_rays ? (const void*)k_trace<false, true> : (const void*)k_trace<false, false>);
+  const void* kshadow = count ? (sort_rays ? (const void*)k_shadow<true, true> : (const void*)k_shadow<true, false>) : (sort_rays ? (const void*)k_shadow<false, true> : (const void*)k_shadow<false, false>);
   if (lds > 156 * 1024) fail(LR_EUNSUPPORTED, "BVH too deep: the per-lane traversal stack does not fit the CU's LDS");
   if (lds > 48 * 1024) {
     HIP_OK(hipFuncSetAttribute(ktrace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -571,20 +631,23 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       q.ds.q_shade += (size_t)kNumShadeQueues * base; q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
       q.ds.q_shadow += (size_t)(kNumShadeQueues - 1) * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
       q.ds.pool += base_seg;
+      if (q.ds.order) { q.ds.order += base; q.ds.sort_key += base; }
       q.ds.n_retired = s.counters.p + 1 + g;
       q.ds.n_slots = q.n_slots; q.ds.n_seg = q.n_seg;
       q.g_trace = grid_for(ktrace, s.n_cus, lds, q.n_seg * kBlock);
       q.g_shadow = grid_for(kshadow, s.n_cus, lds, q.n_seg * kBlock);
-      q.spb = std::min<uint32_t>(kMaxGroup, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
+      uint32_t max_group = kMaxGroup;
+      if (const char* e = std::getenv("LR_MAXGROUP")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxGroup) max_group = (uint32_t)v; }   // diagnostic: shorter passes / smaller sort windows
+      q.spb = std::min<uint32_t>(max_group, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
       q.ds.trace_spb = q.spb;
       q.g_gen = grid_for((const void*)k_generate, s.n_cus, 0, q.n_seg * kBlock);
       const uint32_t n_ranges = (q.n_seg + q.spb - 1) / q.spb;                           // k_shade: one workgroup per trace range
-      q.g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, 0, n_ranges * kBlock);
-      q.g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, 0, n_ranges * kBlock);
-      q.g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, 0, n_ranges * kBlock);
-      q.g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, 0, n_ranges * kBlock);
-      q.g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, 0, n_ranges * kBlock);
-      q.g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, 0, n_ranges * kBlock);
+      q.g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, shade_lds, n_ranges * kBlock);
+      q.g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, shade_lds, n_ranges * kBlock);
+      q.g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, shade_lds, n_ranges * kBlock);
+      q.g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, shade_lds, n_ranges * kBlock);
+      q.g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, shade_lds, n_ranges * kBlock);
+      q.g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, shade_lds, n_ranges * kBlock);
       q.dsc = dsc;
       spill_per_group = std::max<uint32_t>(spill_per_group, (uint32_t)std::max(q.g_trace, q.g_shadow));
     }
@@ -614,17 +677,23 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       for (int k = 0; k < kCheck; ++k) {
         for (int g = 0; g < G; ++g) {
           Group& q = grp[g];
-          if (count) L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<true>, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
-          else L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(k_trace<false>, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
-          if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(q.g_shade[0]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(q.g_shade[1]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(q.g_shade[2]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(q.g_shade[3]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(q.g_shade[4]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-          L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(q.g_shade[5]), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+          auto launch_trace = [&](auto kernel) {
+            L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
+          };
+          if (count) { if (sort_rays) launch_trace(k_trace<true, true>); else launch_trace(k_trace<true, false>); }
+          else { if (sort_rays) launch_trace(k_trace<false, true>); else launch_trace(k_trace<false, false>); }
+          if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(q.g_shade[0]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(q.g_shade[1]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(q.g_shade[2]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(q.g_shade[3]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+          if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(q.g_shade[4]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+          L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(q.g_shade[5]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
           if (nee) {
-            if (count) L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
-            else L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
+            auto launch_shadow = [&](auto kernel) {
+              L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
+            };
+            if (count) { if (sort_rays) launch_shadow(k_shadow<true, true>); else launch_shadow(k_shadow<true, false>); }
+            else { if (sort_rays) launch_shadow(k_shadow<false, true>); else launch_shadow(k_shadow<false, false>); }
           }
         }
         L.iter++; S.iterations++;
@@ -727,7 +796,7 @@ int lr_scene_destroy(LrScene* s) {
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
   s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
-  s->stats_dev.release(); s->film.release(); s->packed.release();
+  s->stats_dev.release(); s->film.release(); s->packed.release(); s->sort_key.release(); s->order.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->host_film) (void)hipHostFree(s->host_film);
   for (auto e : s->poll_ev) if (e) (void)hipEventDestroy(e);
