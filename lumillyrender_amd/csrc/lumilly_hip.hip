@@ -527,7 +527,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.q_shade.ensure((size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
   s.q_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
   s.pool.ensure(n_seg);
-  const bool sort_rays = !resident && s.dev.n_flat == 0 && !(std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 0);
+  // Ray sort before trace / shadow (lr_kernels.h "Ray sort"): measured on the 100k-triangle configs it LOSES 6 % (lanes per
+  // VALU instruction 20.9 -> 23.0, but HBM fetch x3 and L2 hit rate 0.67 -> 0.54: the sorted order gathers 16-B rows from all
+  // over the range), so it is opt-in: LR_SORT=1.  DESIGN.md section 6 has the numbers.
+  const bool sort_rays = !resident && s.dev.n_flat == 0 && std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 1;
   if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
   s.counters.ensure(4);
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 8);
