@@ -36,7 +36,8 @@
 namespace lr {
 
 constexpr int kBlock = 256;            // 4 waves of 64
-constexpr int kStackLdsMax = 25;       // traversal stack entries per lane kept in LDS by the streaming kernels (6 workgroups of 25 KB per CU)
+constexpr int kStackLdsMax = 16;       // traversal stack entries per lane kept in LDS by the streaming kernels; near-first order rarely goes deeper
+                                       // (12 / 16 / 25 entries render the 100k-triangle configs at the same speed), the rest of the worst case spills
 constexpr int kNodeRows = 4;         // float4 rows per 4-wide node (64 B)
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;

@@ -164,6 +164,8 @@ LR_DEV float qbyte(uint32_t w, int k) {                                  // byte
 }
 template <bool SHADOW>
 LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
+  // (Tried: a breadth-first copy of the top 208 nodes in LDS served 78 % of the node fetches and changed nothing -- those
+  //  nodes were L1 hits already; the step is bound by its ~150 dependent VALU instructions, not by the fetch.)
   const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
   float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
   s.visits += 4;
@@ -239,15 +241,39 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
 #define LR_DESCEND_BURST 3
 #endif
 constexpr int kDescendBurst = LR_DESCEND_BURST;
+// LR_DIAG build (make diag): wave-uniform step / lane / cycle counters of the traversal loop, printed by lr_render
+struct TravDiag { unsigned long long node_steps, node_lanes, leaf_steps, leaf_lanes, leaf_prims_max, leaf_prims, cyc_node, cyc_leaf, cyc_retire, cyc_fetch, cyc_total, rays; };
+#ifdef LR_DIAG
+#define LR_DIAG_ONLY(...) __VA_ARGS__
+#else
+#define LR_DIAG_ONLY(...)
+#endif
 template <bool SHADOW>
-LR_DEV void trav_burst(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, bool& go) {
+LR_DEV void trav_burst(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, bool& go, TravDiag* dg = nullptr) {
+  (void)dg;
 #pragma unroll 1
   for (int it = 0; it < kDescendBurst; ++it) {
     bool nm = go && s.cur >= 0;
-    if (__ballot(nm) == 0) break;
+    uint64_t bm = __ballot(nm);
+    if (bm == 0) break;
+    LR_DIAG_ONLY(unsigned long long t0 = __builtin_amdgcn_s_memtime();)
     if (nm) go = trav_node<SHADOW>(sc, s, stk_n);
+    LR_DIAG_ONLY(dg->node_steps += 1; dg->node_lanes += (unsigned)__builtin_popcountll(bm); dg->cyc_node += __builtin_amdgcn_s_memtime() - t0;)
   }
+#ifdef LR_DIAG
+  {
+    bool lm = go && s.cur < 0;
+    uint64_t bl = __ballot(lm);
+    if (bl) {
+      uint32_t cnt = lm ? ((uint32_t)~s.cur & 7u) : 0u, mx = cnt, sm = cnt;
+      for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64)); sm += (uint32_t)__shfl_xor((int)sm, off, 64); }
+      dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(bl); dg->leaf_prims_max += mx; dg->leaf_prims += sm;
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
   if (go && s.cur < 0) go = trav_leaf<SHADOW>(sc, s, stk_n);
+  LR_DIAG_ONLY(dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1;)
 }
 
 template <bool SHADOW>
@@ -981,8 +1007,10 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
       Trav<false> tr;
       bool has = false, fin = false;
       uint32_t slot = 0;
+      LR_DIAG_ONLY(TravDiag dg = {}; unsigned long long tq0 = __builtin_amdgcn_s_memtime(), tq = tq0;)
       while (true) {
         // ---- converged point: retire finished rays (hit record + compaction into the (segment, BSDF) lists) ----
+        LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime();)
         {
           bool f = has && fin;
           int key = -1;
@@ -1003,6 +1031,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           if (f) { has = false; fin = false; }
         }
         // ---- dynamic fetch: free lanes draw the next rays of this workgroup's range ----
+        LR_DIAG_ONLY(dg.cyc_retire += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime();)
         bool need = !has;
         bool exhausted;
         if (sorted) {
@@ -1019,21 +1048,34 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           exhausted = __ballot(need && idx >= total) != 0;           // the dispenser is monotonic: one lane past the end = empty for all
           if (need && idx < total) {
             slot = slot0 + idx;
-            float4 ro = st.ray_o[slot];
+            float4 ro = st.ray_o[slot], rd = st.ray_d[slot];         // both rows in one round trip (a retired slot costs a wasted 16 B, only at the end of a render)
             if (__float_as_int(ro.w) >= 0) {
-              float4 rd = st.ray_d[slot];
               trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
               has = true; n_rays += 1;
             }
           }
         }
+        LR_DIAG_ONLY(dg.cyc_fetch += __builtin_amdgcn_s_memtime() - tq;)
         if (__ballot(has) == 0) { if (exhausted) break; continue; }
         // ---- walk until the wave thins out (or, with nothing left to fetch, until it is done) ----
         const int thresh = exhausted ? 0 : kRefillBelow;
         bool go = has && !fin;
+#ifdef LR_DIAG
+        do { trav_burst<false>(sc, tr, stk_n, go, &dg); } while (__builtin_popcountll(__ballot(go)) > thresh);
+#else
         do { trav_burst<false>(sc, tr, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+#endif
         fin = has && !go;
       }
+#ifdef LR_DIAG
+      dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
+      { uint32_t r = n_rays; for (int off = 32; off > 0; off >>= 1) r += (uint32_t)__shfl_xor((int)r, off, 64); dg.rays = r; }
+      if (lane_id() == 0) {
+        unsigned long long* o = st.stats + (size_t)kStatShards * kStatStride + 8;
+        const unsigned long long* v = (const unsigned long long*)&dg;
+        for (int i = 0; i < (int)(sizeof(TravDiag) / 8); ++i) atomicAdd(o + i, v[i]);
+      }
+#endif
     }
     __syncthreads();
     if (tid < kNumShadeQueues) st.c_shade[tid * st.n_seg + seg0] = s_cnt[tid];      // the range's lists start in its first segment's storage

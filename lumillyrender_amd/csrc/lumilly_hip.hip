@@ -533,7 +533,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const bool sort_rays = !resident && s.dev.n_flat == 0 && std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 1;
   if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
   s.counters.ensure(4);
-  s.stats_dev.ensure((size_t)kStatShards * kStatStride + 8);
+  s.stats_dev.ensure((size_t)kStatShards * kStatStride + 32);
   s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
@@ -574,7 +574,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   S.path_slots = n_slots; S.pipeline = resident ? 1 : 0;
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
-  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 8) * sizeof(unsigned long long), st));
+  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 32) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
   // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (6 workgroups of 25 KB per CU, the
@@ -731,6 +731,19 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     double tot = 0; for (int i = 0; i < 5; ++i) tot += (double)tk[i];
     std::fprintf(stderr, "[LR_STAMP] wave-cycle shares: barrier-wait %.1f%%  pool/zero %.1f%%  trace %.1f%%  shade %.1f%%  shadow %.1f%%\n",
                  100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot);
+  }
+#endif
+#ifdef LR_DIAG
+  {
+    TravDiag d;
+    HIP_OK(hipMemcpy(&d, s.stats_dev.p + (size_t)kStatShards * kStatStride + 8, sizeof(d), hipMemcpyDeviceToHost));
+    if (d.node_steps) std::fprintf(stderr, "[LR_DIAG] k_trace waves: node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes, %.2f prims/lane, max %.2f/step); "
+        "wave cycles: node %.1f%% leaf %.1f%% retire %.1f%% fetch %.1f%% other %.1f%%; per ray: %.2f node-lane-steps %.2f leaf-lane-steps\n",
+        d.node_steps, (double)d.node_lanes / d.node_steps, d.leaf_steps, (double)d.leaf_lanes / std::max<unsigned long long>(d.leaf_steps, 1), (double)d.leaf_prims / std::max<unsigned long long>(d.leaf_lanes, 1),
+        (double)d.leaf_prims_max / std::max<unsigned long long>(d.leaf_steps, 1),
+        100.0 * d.cyc_node / d.cyc_total, 100.0 * d.cyc_leaf / d.cyc_total, 100.0 * d.cyc_retire / d.cyc_total, 100.0 * d.cyc_fetch / d.cyc_total,
+        100.0 * (double)(d.cyc_total - d.cyc_node - d.cyc_leaf - d.cyc_retire - d.cyc_fetch) / d.cyc_total,
+        (double)d.node_lanes / std::max<unsigned long long>(d.rays, 1), (double)d.leaf_lanes / std::max<unsigned long long>(d.rays, 1));
   }
 #endif
   unsigned long long hstats[ST_COUNT] = {0};
