@@ -3,7 +3,7 @@
 //
 //   1. primitive boxes + scene bounds            (triangle.rs:102-118, sphere.rs:31-38)
 //   2. conservative padding, 30-bit Morton codes of the box centres
-//   3. radix sort of (code, primitive)            hipCUB DeviceRadixSort (library sort; not a hot op)
+//   3. radix sort of (code, primitive)            four stable 8-bit passes: per-tile histograms, one scan, ranked scatter (below)
 //   4. Karras 2012 binary radix tree over the sorted codes (ties broken by position)
 //   5. bottom-up box fit + height, agent-scope hand-off between the two children of a node
 //   6. emit the two-boxes-per-node layout of the traversal kernels + primitives in leaf order
@@ -11,9 +11,11 @@
 // The tree only prunes (DESIGN.md "closest-hit semantics"): images are bit-identical to the ones
 // rendered with the host SAH tree; an LBVH is merely ~1.3-2x slower to traverse.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -192,6 +194,73 @@ __global__ void k_emit_prims(const LrPrimitive* prims, const uint32_t* vals, int
   }
 }
 
+// ---- LSD radix sort of (key, value) pairs: 8-bit digits, stable ------------------------------------------------
+// A pass = k_rs_hist (one 256-bin histogram per tile of kRsTile keys, stored bin-major so that one exclusive scan over
+// the whole table yields every tile's first output position per digit) + k_rs_scan + k_rs_scatter (the tile again, in
+// order: a key's rank = keys of its digit in earlier tiles + in earlier rounds / waves of this tile + in lower lanes of its
+// wave, the last one from eight __ballot masks).  Not a hot operation: it runs once per lr_scene_create.
+constexpr int kRsTile = kB * 16;
+__global__ void __launch_bounds__(kB) k_rs_hist(const uint32_t* keys, int n, int shift, int n_tiles, uint32_t* hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kRsTile;
+  for (int r = 0; r < kRsTile / kB; ++r) {
+    int i = base + r * kB + (int)threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(kB) k_rs_scan(uint32_t* hist, int total) {      // one workgroup: exclusive scan in place
+  __shared__ uint32_t s_w[kB / 64];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (int base = 0; base < total; base += kB) {
+    int i = base + (int)threadIdx.x;
+    uint32_t v = i < total ? hist[i] : 0u, x = v;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(x, off, 64); if ((int)lane >= off) x += t; }
+    if (lane == 63u) s_w[wave] = x;
+    __syncthreads();
+    uint32_t pre = s_carry;
+    for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
+    if (i < total) hist[i] = pre + x - v;
+    __syncthreads();
+    if (threadIdx.x == kB - 1) s_carry = pre + x;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(kB) k_rs_scatter(const uint32_t* keys, const uint32_t* vals, int n, int shift, int n_tiles, const uint32_t* hist,
+                                                   uint32_t* keys_out, uint32_t* vals_out) {
+  __shared__ uint32_t s_next[256];                                  // next output position of each digit for this tile
+  s_next[threadIdx.x] = hist[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * kRsTile;
+  for (int r = 0; r < kRsTile / kB; ++r) {
+    int i = base + r * kB + (int)threadIdx.x;
+    const bool valid = i < n;
+    uint32_t k = valid ? keys[i] : 0u, v = valid ? vals[i] : 0u;
+    uint32_t d = (k >> shift) & 0xffu;
+    // lanes of this wave with the same digit
+    uint64_t same = __ballot(valid);
+    for (int b = 0; b < 8; ++b) { uint64_t m = __ballot((d >> b) & 1u); same &= ((d >> b) & 1u) ? m : ~m; }
+    const uint32_t below = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    const uint32_t count = (uint32_t)__builtin_popcountll(same);
+    uint32_t pos = 0;
+    for (uint32_t w = 0; w < kB / 64; ++w) {                        // waves take their positions in order: stable
+      if (wave == w && valid) {
+        pos = s_next[d] + below;
+        if (below == 0) s_next[d] += count;                         // one lane per digit group (all read before any adds: one wave instruction each)
+      }
+      __syncthreads();
+    }
+    if (valid) { keys_out[pos] = k; vals_out[pos] = v; }
+  }
+}
+
 struct Tmp {
   std::vector<void*> ptrs;
   template <class T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(p); return (T*)p; }
@@ -244,11 +313,35 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
   float inv[3];
   for (int a = 0; a < 3; ++a) inv[a] = hi[a] > lo[a] ? 1.0f / (hi[a] - lo[a]) : 0.0f;
   hipLaunchKernelGGL(k_pad_morton, dim3(grid), dim3(kB), 0, st, d_in, n, boxes, pad, diag, lo[0], lo[1], lo[2], inv[0], inv[1], inv[2], keys, vals);
-  size_t sort_bytes = 0;
-  LB_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys2, vals, vals2, n, 0, 30, st));
-  void* sort_tmp = tmp.get<char>(sort_bytes);
-  if (!sort_tmp) { err = "out of device memory"; return LR_ENOMEM; }
-  LB_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys2, vals, vals2, n, 0, 30, st));
+  {
+    // sort (code, primitive) by code: 30 bits = four 8-bit passes, ping-pong; the sorted arrays end in keys2 / vals2
+    const int n_tiles = (n + kRsTile - 1) / kRsTile;
+    uint32_t* hist = tmp.get<uint32_t>((size_t)256 * n_tiles);
+    if (!hist) { err = "out of device memory"; return LR_ENOMEM; }
+    uint32_t *ka = keys, *va = vals, *kb = keys2, *vb = vals2;
+    for (int pass = 0; pass < 4; ++pass) {
+      hipLaunchKernelGGL(k_rs_hist, dim3(n_tiles), dim3(kB), 0, st, ka, n, 8 * pass, n_tiles, hist);
+      hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(kB), 0, st, hist, 256 * n_tiles);
+      hipLaunchKernelGGL(k_rs_scatter, dim3(n_tiles), dim3(kB), 0, st, ka, va, n, 8 * pass, n_tiles, hist, kb, vb);
+      std::swap(ka, kb); std::swap(va, vb);
+    }
+    // four passes: the result is back in (keys, vals); the tree kernels read keys2 / vals2
+    LB_OK(hipMemcpyAsync(keys2, keys, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    LB_OK(hipMemcpyAsync(vals2, vals, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    LB_OK(hipGetLastError());
+    if (std::getenv("LR_DEBUG")) {                                  // self-check: sorted codes, values a permutation of 0..n-1
+      std::vector<uint32_t> hk((size_t)n), hv((size_t)n);
+      LB_OK(hipMemcpyAsync(hk.data(), keys2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+      LB_OK(hipMemcpyAsync(hv.data(), vals2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+      LB_OK(hipStreamSynchronize(st));
+      std::vector<char> seen((size_t)n, 0);
+      for (int i = 0; i < n; ++i) {
+        if ((i > 0 && hk[i] < hk[i - 1]) || hv[i] >= (uint32_t)n || seen[hv[i]]) { err = "radix sort self-check failed at " + std::to_string(i); return LR_EDEVICE; }
+        seen[hv[i]] = 1;
+      }
+      std::fprintf(stderr, "[lr] lbvh: radix sort of %d codes verified\n", n);
+    }
+  }
   LB_OK(hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), st));
   LB_OK(hipMemsetAsync(height, 0, (size_t)n * sizeof(int), st));
   hipLaunchKernelGGL(k_radix_tree, dim3(grid), dim3(kB), 0, st, keys2, n, children, node_parent, leaf_parent);
