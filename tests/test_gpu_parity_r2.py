@@ -400,3 +400,75 @@ def test_two_rank_bench_assembles_the_single_rank_film(tmp_path):
     line = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["spp"] == 16
     assert line["rank_render_ms"]["max"] >= line["rank_render_ms"]["min"] > 0
+
+
+# ---- switches that must not change a film; boundary checks added in round 2 ----------------------------------------
+
+def test_sorted_and_unordered_variants_are_bit_identical(dev, monkeypatch):
+    """LR_SORT=1 (rays binned by octant / origin cell before trace and shadow) and LR_SHADE_ORDER=0 (shade in list order)
+    only change which lane handles which ray or vertex: same films, same counters, on the mesh scenes where they apply."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    from lumillyrender_amd import abi
+    for name, spp in (("mesh-box.toml", 24), ("ibl-lens.toml", 16)):
+        desc = load(name, 160, 120)                     # 19200 pixels: several ranges, so the sort window is exercised with real lists
+        scene = dev.Scene(desc)
+        p = desc.render_params(spp=spp, seed=41, flags=abi.LR_FLAG_STREAMING)
+        base = scene.render(p)
+        st0 = scene.stats()
+        for env in ({"LR_SORT": "1"}, {"LR_SHADE_ORDER": "0"}, {"LR_SORT": "1", "LR_SHADE_ORDER": "0", "LR_MAXGROUP": "2"}, {"LR_GROUPS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            img = scene.render(p)
+            st = scene.stats()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(img, base), (name, env)
+            assert (st.samples, st.segments, st.shadow_rays, st.sky_fetches) == (st0.samples, st0.segments, st0.shadow_rays, st0.sky_fetches), (name, env)
+        scene.close()
+
+
+def test_round2_boundary_checks(dev):
+    """a BVH that is a DAG, overlapping tiles, a film of the wrong shape / dtype / layout are refused with an
+    error code or a ValueError instead of being expanded exponentially, rendered twice or written out of bounds."""
+    import ctypes as C
+    from lumillyrender_amd import abi, host
+    desc = load("cbox-spheres.toml", 32, 24)
+    d = desc.desc
+    lib = dev.lib()
+    # two parents for one node
+    nodes = (abi.LrBvhNode * d.n_bvh_nodes)()
+    C.memmove(nodes, d.bvh_nodes, C.sizeof(nodes))
+    inner = [(i, c) for i in range(d.n_bvh_nodes) for c in range(2) if nodes[i].child[c] >= 0]
+    assert len(inner) >= 2
+    (i0, c0), (i1, c1) = inner[0], inner[1]
+    nodes[i1].child[c1] = nodes[i0].child[c0] if nodes[i0].child[c0] > i1 else nodes[i1].child[c1]
+    if nodes[i1].child[c1] == nodes[i0].child[c0]:
+        bad = abi.LrSceneDesc.from_buffer_copy(d)
+        bad.bvh_nodes = C.cast(nodes, C.POINTER(abi.LrBvhNode))
+        h = C.c_void_p()
+        assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
+        assert b"two parents" in lib.lr_last_error() or b"parent" in lib.lr_last_error() or b"primitive" in lib.lr_last_error()
+    scene = dev.Scene(desc)
+    params = desc.render_params(spp=2, seed=1)
+    # overlapping tiles
+    tiles = (abi.LrTile * 2)()
+    tiles[0].x0, tiles[0].y0, tiles[0].w, tiles[0].h = 0, 0, 20, 12
+    tiles[1].x0, tiles[1].y0, tiles[1].w, tiles[1].h = 19, 11, 5, 5
+    with pytest.raises(host.LumillyError, match="overlap"):
+        scene.render(params, tiles, 2)
+    tiles[1].x0 = 20                                                   # abutting is fine
+    scene.render(params, tiles, 2)
+    # films the native side must never see
+    with pytest.raises(ValueError):
+        scene.render(params, out=np.zeros((24, 32, 3), dtype=np.float64))
+    with pytest.raises(ValueError):
+        scene.render(params, out=np.zeros((32, 24, 3), dtype=np.float32))
+    with pytest.raises(ValueError):
+        scene.render(params, out=np.zeros((24, 64, 3), dtype=np.float32)[:, ::2])
+    with pytest.raises(ValueError):
+        scene.render(params, tiles, 3)                                  # more tiles than the array holds
+    with pytest.raises(ValueError):
+        scene.intersect(np.zeros((4, 3), np.float32), np.zeros((5, 3), np.float32))
+    assert np.isfinite(scene.render(params)).all()
+    scene.close()
