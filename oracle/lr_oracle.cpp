@@ -813,7 +813,8 @@ struct Scene {
       // "optimized" CPU baseline: the same tree, walked near child first with an explicit
       // stack, subtrees entered beyond the best hit so far are skipped, no candidate vector.  Boxes only prune
       // (pad > 0 keeps them conservative), ties go to the lowest primitive index: same result as mode 0.
-      int stack[128]; float stack_t[128]; int sp = 0;
+      int stack[256]; float stack_t[256]; int sp = 0;
+      bool overflow = false;
       V3 inv_d = v3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
       float te;
       if (bvh.root >= 0 && BVH::aabb_entry(bvh.nodes[bvh.root].box, ray, inv_d, pad, &te)) { stack[sp] = bvh.root; stack_t[sp++] = te; }
@@ -841,7 +842,16 @@ struct Scene {
           else { stack[sp] = b.left; stack_t[sp++] = tl; stack[sp] = b.right; stack_t[sp++] = tr; }
         } else if (hl) { stack[sp] = b.left; stack_t[sp++] = tl; }
         else if (hr) { stack[sp] = b.right; stack_t[sp++] = tr; }
-        if (sp > 120) return false;                                              // cannot happen for SAH trees of < 2^60 leaves
+        if (sp > 250) { overflow = true; break; }                                 // a pathologically deep tree: redo this ray the literal way below
+      }
+      if (overflow) {
+        found = false; best.distance = 0.0f; best.prim = -1;
+        std::vector<int> cand;
+        bvh.may_intersect(bvh.root, ray, pad, cand, nullptr);
+        for (size_t k = 0; k < cand.size(); ++k) {
+          Intersection it; int i = cand[k];
+          if (prim_intersect(prims[i], ray, &it) && (!found || it.distance < best.distance || (it.distance == best.distance && i < best.prim))) { best = it; best.prim = i; found = true; }
+        }
       }
     } else {
       std::vector<int> cand;
