@@ -120,9 +120,10 @@ def cpu_baseline(desc, W, H, integ, cpu_seconds):
 
 
 def load_profile(kind, cfg, want):
-    """Newest profiles/r*_{kind}_{cfg}.json whose recorded workload equals `want` on every key of `want`
-    (scene, film size, spp, slot count); None when there is none -- a figure from another workload is never attached."""
-    best = None
+    """Newest (by the `when` stamp the export recorded, then by name) profiles/r*_{kind}_{cfg}.json whose recorded workload
+    equals `want` on every key of `want` (scene, film size, spp, slot count); None when there is none -- a figure from
+    another workload is never attached."""
+    best, best_key = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_{cfg}.json"))):
         try:
             d = json.load(open(path))
@@ -130,7 +131,9 @@ def load_profile(kind, cfg, want):
             continue
         wl = d.get("workload", {})
         if all(str(wl.get(k)) == str(v) for k, v in want.items()):
-            best = (path, d)
+            key = (int(wl.get("when", 0) or 0), os.path.basename(path))
+            if best_key is None or key > best_key:
+                best, best_key = (path, d), key
     return best
 
 

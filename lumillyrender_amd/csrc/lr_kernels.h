@@ -19,6 +19,7 @@
 //                light-side cosine and emission of the surface actually hit
 //   k_resolve    main.rs:104,121 + img.rs:25-27: chunk sums -> pixel mean -> film
 #pragma once
+#include <type_traits>
 #include "lr_math.h"
 #include "lr_device.h"
 
@@ -1411,12 +1412,12 @@ LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t b
 // The lists of one iteration are cut into 64-entry chunks and the chunks of ALL lists are dealt round-robin to the
 // four waves (*next_chunk carries the running chunk number from list to list): with one wave per list start, a
 // scene with five BSDFs of ~40 hits each would run its whole shade phase on wave 0.
-template <int MT>
+template <int MT, int RB, class LT>
 LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const DevParams& rp,
-                                const uint8_t* list, uint32_t n, uint8_t* shadow_list, uint32_t* shadow_cnt,
-                                uint8_t* finish_list, uint32_t* finish_cnt, uint32_t wave, uint32_t lane, uint32_t* next_chunk) {
+                                const LT* list, uint32_t n, LT* shadow_list, uint32_t* shadow_cnt,
+                                LT* finish_list, uint32_t* finish_cnt, uint32_t wave, uint32_t lane, uint32_t* next_chunk) {
   const uint32_t chunks = (n + 63u) >> 6;
-  for (uint32_t c = (wave - *next_chunk) & (kBlock / 64 - 1); c < chunks; c += kBlock / 64) {
+  for (uint32_t c = (wave - *next_chunk) & (RB / 64 - 1); c < chunks; c += RB / 64) {
     uint32_t i = c * 64u + lane;
     bool valid = i < n;
     uint32_t slot = valid ? list[i] : 0;
@@ -1425,16 +1426,22 @@ LR_DEV void resident_shade_list(const DevScene& sc, const DevState& st, const De
     // a path that ended here (Russian roulette) leaves its final radiance in the slot and queues for the finish pass
     if (v.finished) st.rad[slot] = make_float4(v.L.x, v.L.y, v.L.z, __uint_as_float(v.sample));
     uint32_t fidx = wave_reserve(finish_cnt, v.finished);
-    if (v.finished) finish_list[fidx] = (uint8_t)slot;
+    if (v.finished) finish_list[fidx] = (LT)slot;
     uint32_t idx = wave_reserve(shadow_cnt, v.has_shadow);
-    if (v.has_shadow) shadow_list[idx] = (uint8_t)slot;
+    if (v.has_shadow) shadow_list[idx] = (LT)slot;
   }
   *next_chunk += chunks;
 }
 
-constexpr int kRSeg = 256;               // slots per resident workgroup (one per thread)
-constexpr int kResidentStateBytes = 6 * kRSeg * 16 + 7 * kRSeg;   // ray_o ray_d thr rad sh_d sh_w(+hit) | 7 byte lists: 25.75 KB, six workgroups per CU
-static_assert(kRSeg <= 256, "slot numbers are stored in bytes");
+// Slots per resident workgroup = its thread count RB: 256 (4 waves, slot numbers in bytes, 25.75 KB: six workgroups per
+// CU) or, for flat scenes whose lists fit, 512 (8 waves, 16-bit slot numbers, <= 53 KB: three per CU -- the same 24 waves).
+// A phase cuts each list into 64-entry chunks, and on average half a chunk per list runs on dead lanes: with twice the
+// slots per workgroup the lists are twice as long and that waste halves.  Chosen by the host for scenes with several BSDF
+// lists (BRDF row: +3.9 %); the Lambert-only headline scene is 2.5 % faster with 256.  Lists are allocated only for the
+// BSDFs present (+ shadow + finish).
+constexpr int kRSeg = 256;               // the small form; also the unit n_slots is rounded to
+LR_DEV constexpr int resident_state_bytes(int rb, int n_lists) { return 6 * rb * 16 + n_lists * rb * (rb > 256 ? 2 : 1); }
+inline int resident_lds_bytes(int rb, int n_lists) { return 6 * rb * 16 + n_lists * rb * (rb > 256 ? 2 : 1); }
 
 #ifndef LR_RES_WAVES
 #define LR_RES_WAVES 6
@@ -1443,8 +1450,10 @@ static_assert(kRSeg <= 256, "slot numbers are stored in bytes");
 // register allocation is not burdened by the 4-wide node step it never runs.
 // MTS: the BSDF bodies compiled in (bit k = LR_MAT_* k); the Lambert-only instantiation (the headline scene class)
 // allocates registers for one shading body instead of the most demanding of five.
-template <bool FLAT, uint32_t MTS>
-__global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+template <bool FLAT, uint32_t MTS, int RB>
+__global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevState gst, DevParams rp, uint32_t mt_mask, const float4* __restrict__ flat_prims) {
+  static_assert(RB == 256 || (RB == 512 && FLAT), "the traversal stack is laid out for 256-thread workgroups");
+  typedef typename std::conditional<(RB > 256), uint16_t, uint8_t>::type LT;      // list entry = slot number
   extern __shared__ float4 lds4[];
   __shared__ PoolLds pl;
   __shared__ uint32_t s_cnt2[2][8];        // list lengths, double-buffered by iteration parity: [0..4] shade lists, [6] shadow list, [7] finish list
@@ -1452,22 +1461,26 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
   __shared__ uint32_t s_stat[ST_COUNT];
   __shared__ uint8_t s_qid[kFlatMax];
   DevState st = gst;
-  st.ray_o = lds4; st.ray_d = lds4 + kRSeg; st.thr = lds4 + 2 * kRSeg; st.rad = lds4 + 3 * kRSeg;
-  st.sh_d = lds4 + 4 * kRSeg; st.sh_w = lds4 + 5 * kRSeg;
-  st.acc = gst.acc + (size_t)blockIdx.x * kRSeg;                    // chunk sums are touched once per finished sample: they stay in HBM/L2
+  st.ray_o = lds4; st.ray_d = lds4 + RB; st.thr = lds4 + 2 * RB; st.rad = lds4 + 3 * RB;
+  st.sh_d = lds4 + 4 * RB; st.sh_w = lds4 + 5 * RB;
+  st.acc = gst.acc + (size_t)blockIdx.x * RB;                    // chunk sums are touched once per finished sample: they stay in HBM/L2
   st.hit = nullptr;                                                 // {t, prim} of a slot is kept in sh_w[slot].xy between trace and shade (sh_w is dead then)
-  uint8_t* lists = (uint8_t*)(lds4 + 6 * kRSeg);                    // [7][kRSeg] slot numbers < 256: 5 BSDF lists, shadow list, finish list
-  uint32_t* stk_n = (uint32_t*)(lists + 7 * kRSeg);
-  uint8_t* shq = lists + 5 * kRSeg;
-  uint8_t* finq = lists + 6 * kRSeg;
+  // lists of slot numbers, one per BSDF present in the scene, then the shadow list and the finish list
+  LT* lists = (LT*)(lds4 + 6 * RB);
+  const uint32_t present = mt_mask & MTS;
+  const uint32_t n_b = (uint32_t)__builtin_popcount(present);
+  auto lpos = [&](int q) { return (uint32_t)__builtin_popcount(present & ((1u << q) - 1u)); };
+  uint32_t* stk_n = (uint32_t*)(lists + (n_b + 2) * RB);
+  LT* shq = lists + n_b * RB;
+  LT* finq = lists + (n_b + 1) * RB;
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
   if (tid < ST_COUNT) s_stat[tid] = 0;
   if (tid < 16) s_cnt2[tid >> 3][tid & 7] = 0;
   if ((int)tid < sc.n_flat) s_qid[tid] = sc.prim_qid[tid];          // flat scenes: the BSDF id of a hit comes from LDS, not from an L2 round trip
-  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, kRSeg, kRSeg); s_retired = 0; }   // first fill: one item per slot
+  if (tid == 0) { pl.r0 = pl.a0 = pl.r1 = pl.a1 = pl.taken = 0; pool_step(st, &pl, RB, RB); s_retired = 0; }   // first fill: one item per slot
   __syncthreads();
-  for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
+  for (uint32_t step = 0; step < 1; ++step) {
     bool r = finish_and_regenerate(sc, st, rp, &pl, step * kBlock + tid, false, true, v3(0, 0, 0), 1.0f, 0, 0);
     (void)wave_reserve(&s_retired, r);
   }
@@ -1484,12 +1497,12 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     __syncthreads();                                                // previous iteration (or generation) complete
     LR_TICK(0)
     const uint32_t retired = s_retired;
-    if (retired >= (uint32_t)kRSeg) break;                          // wave-uniform
+    if (retired >= (uint32_t)RB) break;                          // wave-uniform
     uint32_t* s_cnt = s_cnt2[parity];
     uint32_t* s_cnt_next = s_cnt2[parity ^ 1u];
     parity ^= 1u;
     // ---- phase 1: closest hit for every live slot, compaction by BSDF ----
-    for (uint32_t step = 0; step < kRSeg / kBlock; ++step) {
+    for (uint32_t step = 0; step < 1; ++step) {
       uint32_t slot = step * kBlock + tid;
       bool active = false; int qid = -1;
       float4 ro = st.ray_o[slot];
@@ -1509,7 +1522,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
       {
         bool miss = active && qid == kQMiss;
         uint32_t fidx = wave_reserve(&s_cnt[7], miss);
-        if (miss) { finq[fidx] = (uint8_t)slot; active = false; }
+        if (miss) { finq[fidx] = (LT)slot; active = false; }
       }
       uint64_t todo = __ballot(active);
       while (todo) {
@@ -1517,7 +1530,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
         int q = __shfl(qid, lead, 64);
         bool mine = active && qid == q;
         uint32_t idx = wave_reserve(&s_cnt[q], mine);
-        if (mine) lists[q * kRSeg + idx] = (uint8_t)slot;
+        if (mine) lists[lpos(q) * RB + idx] = (LT)slot;
         todo &= ~__ballot(mine);
       }
     }
@@ -1527,13 +1540,13 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     // ---- phase 2: one BSDF-specialised body per list ----
     // nobody draws work items in this phase, so the last thread (its wave has the least shade work: the lists fill
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
-    if (tid == kBlock - 1) pool_step(st, &pl, st.pool_low, st.pool_batch);   // sized by the host, see DevState
+    if (tid == RB - 1) pool_step(st, &pl, st.pool_low, st.pool_batch);   // sized by the host, see DevState
     uint32_t next_chunk = 0;
-    if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0>(sc, st, rp, lists + 0 * kRSeg, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1>(sc, st, rp, lists + 1 * kRSeg, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 4u) && (mt_mask & 4u)) resident_shade_list<2>(sc, st, rp, lists + 2 * kRSeg, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 8u) && (mt_mask & 8u)) resident_shade_list<3>(sc, st, rp, lists + 3 * kRSeg, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 16u) && (mt_mask & 16u)) resident_shade_list<4>(sc, st, rp, lists + 4 * kRSeg, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0, RB, LT>(sc, st, rp, lists + lpos(0) * RB, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1, RB, LT>(sc, st, rp, lists + lpos(1) * RB, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 4u) && (mt_mask & 4u)) resident_shade_list<2, RB, LT>(sc, st, rp, lists + lpos(2) * RB, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 8u) && (mt_mask & 8u)) resident_shade_list<3, RB, LT>(sc, st, rp, lists + lpos(3) * RB, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 16u) && (mt_mask & 16u)) resident_shade_list<4, RB, LT>(sc, st, rp, lists + lpos(4) * RB, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     LR_TICK(3)
     __syncthreads();
     LR_TICK(0)
@@ -1544,7 +1557,7 @@ __global__ void __launch_bounds__(kBlock, LR_RES_WAVES) k_resident(DevScene sc, 
     const uint32_t nsh = s_cnt[6], nfin = s_cnt[7];
     if (tid < 8) s_cnt_next[tid] = 0;                               // the other parity's counters are idle during this iteration
     const uint32_t wsh = (nsh + 63u) >> 6, wfin = (nfin + 63u) >> 6;
-    for (uint32_t v = wave; v < wsh + wfin; v += kBlock / 64) {
+    for (uint32_t v = wave; v < wsh + wfin; v += RB / 64) {
       if (v < wsh) {
         uint32_t i = v * 64u + lane;
         if (i < nsh) {

@@ -506,17 +506,29 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // pipeline: resident (one launch, path state in LDS) when state + traversal stack stay under 40 KB per workgroup
   // (>= 4 workgroups per CU; 6 for flat scenes), streaming otherwise
   const size_t stack_lds = s.dev.n_flat > 0 ? 0 : (size_t)s.stack_depth * kBlock * 4;   // resident: the whole stack in LDS
-  const size_t resident_lds = (size_t)kResidentStateBytes + stack_lds;
-  bool resident = resident_lds <= 40 * 1024 && !count;
+  uint32_t present_mask = 0;
+  for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) present_mask |= 1u << k;
+  const int n_lists = __builtin_popcount(present_mask) + 2;                 // one list per BSDF present + shadow + finish
+  // flat scenes with SEVERAL BSDF lists, whose lists leave room, run 512-slot workgroups (three per CU = the same 24 waves;
+  // lr_kernels.h kRSeg): measured +3.9 % on the BRDF row (four lists), but -2.5 % on the Lambert-only headline scene, where
+  // there is little chunk waste to win and the 8-wave barriers cost more than they save
+  bool big_block = s.dev.n_flat > 0 && n_lists >= 4 && (size_t)3 * (resident_lds_bytes(512, n_lists) + 512) <= 160 * 1024;
+  if (const char* e = std::getenv("LR_RES_BLOCK")) {                                       // diagnostic override
+    if (std::atoi(e) == 256) big_block = false;
+    if (std::atoi(e) == 512 && s.dev.n_flat > 0 && (size_t)3 * (resident_lds_bytes(512, n_lists) + 512) <= 160 * 1024) big_block = true;
+  }
+  const int RB = big_block ? 512 : 256;
+  const size_t resident_lds = (size_t)resident_lds_bytes(RB, n_lists) + stack_lds;
+  bool resident = resident_lds <= (big_block ? 54 : 40) * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
-  const int resident_per_cu = std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
+  const int resident_per_cu = big_block ? 3 : std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
   // streaming: enough slots that a k_trace workgroup pass covers many rays per lane (the run-down of a pass's last
   // rays is what idles lanes: 1 M slots = 4 rays per lane left 23 % of the lanes busy in a node step), but no more
   // than 1/8 of the work items so that the render as a whole still has many iterations; 136 B of state per slot (<= 32 M slots)
   const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(32u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
-  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * kRSeg) : stream_slots);
-  if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * kRSeg));   // every workgroup must be resident: no grid-stride
+  uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * RB) : stream_slots);
+  if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * RB));   // every workgroup must be resident: no grid-stride
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -561,7 +573,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
   {
-    const uint64_t per_block = n_items64 / (4ull * std::max<uint32_t>(1u, n_slots / kRSeg));
+    const uint64_t per_block = n_items64 / (4ull * std::max<uint32_t>(1u, n_slots / kRSeg));   // per 256 slots (a 512-slot workgroup refills twice as much: below)
     ds.pool_batch = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(64, per_block));
     ds.pool_low = ds.pool_batch >= 128 ? ds.pool_batch / 2 : 24;
   }
@@ -595,13 +607,14 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+    if (RB == 512) { ds.pool_batch *= 2; ds.pool_low *= 2; }
     auto launch_resident = [&](auto kernel) {
       HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / kRSeg), dim3(kBlock), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
+      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / RB), dim3(RB), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
     };
-    if (s.dev.n_flat > 0 && mt_mask == 1u) launch_resident(k_resident<true, 1u>);        // flat, Lambert only
-    else if (s.dev.n_flat > 0) launch_resident(k_resident<true, 31u>);
-    else launch_resident(k_resident<false, 31u>);
+    if (s.dev.n_flat > 0 && mt_mask == 1u) { if (RB == 512) launch_resident(k_resident<true, 1u, 512>); else launch_resident(k_resident<true, 1u, 256>); }   // flat, Lambert only
+    else if (s.dev.n_flat > 0) { if (RB == 512) launch_resident(k_resident<true, 31u, 512>); else launch_resident(k_resident<true, 31u, 256>); }
+    else launch_resident(k_resident<false, 31u, 256>);
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0) {

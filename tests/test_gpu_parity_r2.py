@@ -428,6 +428,25 @@ def test_sorted_and_unordered_variants_are_bit_identical(dev, monkeypatch):
         scene.close()
 
 
+def test_resident_workgroup_sizes_are_bit_identical(dev, oracle, monkeypatch):
+    """The resident kernel runs 256- or 512-slot workgroups (the host picks 512 for flat scenes with several BSDF lists):
+    slots, chunking and RNG keys do not depend on it, so the films are the same bits -- and match the oracle."""
+    from lumillyrender_amd import abi
+    for name, integ in (("brdf-row.toml", 1), ("cbox-spheres.toml", 1), ("two-spheres.toml", None)):
+        desc = load(name, 72, 40)
+        scene = dev.Scene(desc)
+        films = []
+        for rb in ("256", "512"):
+            monkeypatch.setenv("LR_RES_BLOCK", rb)
+            films.append(scene.render(desc.render_params(spp=24, seed=17, integrator=integ, flags=abi.LR_FLAG_RESIDENT)))
+            assert scene.stats().pipeline == 1
+        monkeypatch.delenv("LR_RES_BLOCK")
+        assert np.array_equal(films[0], films[1]), name
+        ref = oracle.render(desc, desc.render_params(spp=24, seed=17, integrator=integ))
+        assert float(np.max(np.abs(films[1] - ref))) < TOL
+        scene.close()
+
+
 def test_round2_boundary_checks(dev):
     """a BVH that is a DAG, overlapping tiles, a film of the wrong shape / dtype / layout are refused with an
     error code or a ValueError instead of being expanded exponentially, rendered twice or written out of bounds."""
