@@ -1,0 +1,46 @@
+"""bench.py attaches a rocprofv3 figure (HBM traffic, VALU instructions) to its JSON line only when the committed profile was
+taken on THIS workload (a stale file must never be mixed with the current timing), and takes the newest one."""
+import importlib.util
+import json
+import os
+
+from tests.conftest import ROOT
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_profile_is_attached_only_for_the_same_workload(tmp_path, monkeypatch):
+    b = _bench()
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    wl = {"config": "c2", "scene": "cbox-spheres.toml", "width": 1024, "height": 1024, "spp": 1024, "path_slots": 393216}
+    json.dump({"workload": dict(wl, when=100), "k_resident_hbm_bytes_per_launch": 1}, open(tmp_path / "profiles" / "r02b_traffic_c2.json", "w"))
+    json.dump({"workload": dict(wl, when=200), "k_resident_hbm_bytes_per_launch": 2}, open(tmp_path / "profiles" / "r02_traffic_c2.json", "w"))
+    json.dump({"workload": dict(wl, spp=256, when=300), "k_resident_hbm_bytes_per_launch": 3}, open(tmp_path / "profiles" / "r03_traffic_c2.json", "w"))
+    json.dump({"note": "no workload recorded", "k_resident_hbm_bytes_per_launch": 4}, open(tmp_path / "profiles" / "r04_traffic_c2.json", "w"))
+    want = {"scene": "cbox-spheres.toml", "width": 1024, "height": 1024, "spp": 1024}
+    path, d = b.load_profile("traffic", "c2", want)
+    assert os.path.basename(path) == "r02_traffic_c2.json" and d["k_resident_hbm_bytes_per_launch"] == 2      # newest stamp wins, not the last name
+    assert b.load_profile("traffic", "c2", dict(want, spp=512)) is None                                          # another spp: nothing attached
+    assert b.load_profile("traffic", "c2", dict(want, scene="brdf-row.toml")) is None
+    assert b.load_profile("traffic", "c3", want) is None
+    assert b.load_profile("pmc", "c2", want) is None
+
+
+def test_committed_profiles_name_their_workload():
+    """Every traffic / pmc file the bench may pick up records scene, film size and spp or slot count."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_c*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c*.json"))
+    assert files
+    for f in files:
+        wl = json.load(open(f)).get("workload", {})
+        assert {"scene", "width", "height", "spp"} <= set(wl), f
+    b = _bench()
+    for cfg, (scene, w, h, spp, *_rest) in b.CONFIGS.items():
+        want = {"scene": scene, "width": w, "height": h}
+        assert b.load_profile("traffic", cfg, want) is not None, cfg          # each BASELINE config has its HBM report
