@@ -1121,8 +1121,12 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
     V3 out_ = -d;
     V3 emission = v3(m.m1);
     bool no_emission = nee_mode && depth > 0;                      // scene.rs:189 passes `true` below depth 0
-    if (!(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f)   // scene.rs:155-159 / :175-179
-      L = L + T * emission;
+    // scene.rs:155-159 / :175-179: l_e is the emission or ZERO, and the recursion multiplies it by every factor above it
+    // (`l_e + (.. + brdf * coef * L_i * cos / pdf) / p`).  Adding T * 0 changes nothing while T is finite, but once a factor
+    // was inf or NaN (a sampled direction whose pdf underflowed to 0: 0 * c / 0) the reference's pixel is NaN whatever the
+    // rest of the path returns -- the throughput form must poison the sample the same way (found by the fuzzer, seed 400649)
+    const bool emits = !(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f;
+    L = L + T * (emits ? emission : v3(0.0f, 0.0f, 0.0f));
     float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
     Draw4 d1 = rng_block(rp.seed, out.pixel, out.sample, 1u + 2u * (uint32_t)depth);
     if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184

@@ -71,8 +71,8 @@ struct EventPool {
 struct LrScene {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;       // second slot group of the streaming pipeline (render_impl)
-  hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [2] setup done, [3] group 1 batch done
+  hipStream_t gstream[2] = {nullptr, nullptr};   // streams of the 2nd and 3rd slot group of the streaming pipeline (render_impl)
+  hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] setup done, [1], [2] group 1 / 2 batch done
   int n_cus = 0;
   // scene blob
   DevBuf<float4> nodes, prims, flat, shade, emit, texels;
@@ -93,7 +93,7 @@ struct LrScene {
   DevBuf<unsigned long long> stats_dev;
   DevBuf<float> film;
   DevBuf<float> packed;                // the rendered tiles' pixels in pixel-rank order (lr_render reads back only these)
-  uint32_t* pinned = nullptr;         // [0..3] retired-slot read-backs (two polls x two slot groups), [8..] stats
+  uint32_t* pinned = nullptr;         // [0..2], [4..6] retired-slot read-backs (two polls x up to three slot groups), [8..] stats
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
   hipEvent_t t_begin = nullptr, t_end = nullptr;
   EventPool pools[LR_K_COUNT];
@@ -623,24 +623,22 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     // (+10 % on the mesh configs, free-running; chaining the traces with events so that they alternate strictly,
     // or halving the grids, was slower).  The groups share the item dispenser, the chunk sums and the statistics;
     // everything indexed by slot or segment is split.  Small jobs and the counting mode keep one group.
+    constexpr int kMaxGroups = 3;
     int G = (!count && n_seg >= 64) ? 2 : 1;
-    if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || (v == 2 && n_seg >= 2)) G = v; }
-    if (G == 2 && !s.stream2) {
-      HIP_OK(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
-      for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
+    for (int g = 1; g < G; ++g) if (!s.gstream[g - 1]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[g - 1], hipStreamNonBlocking));
+    if (G > 1 && !s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     struct Group {
       DevState ds; DevScene dsc; hipStream_t st; uint32_t n_slots, n_seg, spb; int g_trace, g_shadow, g_gen, g_shade[kNumShadeQueues];
-    } grp[2];
+    } grp[kMaxGroups];
     uint32_t spill_per_group = 0;
     for (int g = 0; g < G; ++g) {
       Group& q = grp[g];
-      const uint32_t seg_a = G == 2 ? n_seg / 2 : n_seg;
-      const uint32_t base_seg = g == 0 ? 0u : seg_a;
-      q.n_seg = g == 0 ? seg_a : n_seg - seg_a;
+      const uint32_t base_seg = (uint32_t)((uint64_t)n_seg * g / G);
+      q.n_seg = (uint32_t)((uint64_t)n_seg * (g + 1) / G) - base_seg;
       q.n_slots = q.n_seg * kSeg;
       const size_t base = (size_t)base_seg * kSeg;
-      q.st = g == 0 ? st : s.stream2;
+      q.st = g == 0 ? st : s.gstream[g - 1];
       q.ds = ds;
       q.ds.ray_o += base; q.ds.ray_d += base; q.ds.hit += base; q.ds.thr += base; q.ds.rad += base; q.ds.acc += base;
       q.ds.sh_d += base; q.ds.sh_w += base;
@@ -672,7 +670,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       s.stack_spill.ensure(per * G);
       for (int g = 0; g < G; ++g) grp[g].dsc.stack_spill = s.stack_spill.p + per * g;
     }
-    if (G == 2) { HIP_OK(hipEventRecord(s.grp_ev[2], st)); HIP_OK(hipStreamWaitEvent(s.stream2, s.grp_ev[2], 0)); }   // uploads, memsets, rank table
+    if (G > 1) { HIP_OK(hipEventRecord(s.grp_ev[0], st)); for (int g = 1; g < G; ++g) HIP_OK(hipStreamWaitEvent(s.gstream[g - 1], s.grp_ev[0], 0)); }   // uploads, memsets, rank table
     for (int g = 0; g < G; ++g) {
       Group& q = grp[g];
       L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(q.g_gen), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
@@ -686,8 +684,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
     // length statistically, this bounds the loop against a logic error
     const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
-    auto retired_all = [&](const uint32_t* two) {
-      return two[0] >= grp[0].n_slots && (G == 1 || two[1] >= grp[1].n_slots);
+    auto retired_all = [&](const uint32_t* per_group) {
+      for (int g = 0; g < G; ++g) if (per_group[g] < grp[g].n_slots) return false;
+      return true;
     };
     while (!done) {
       for (int k = 0; k < kCheck; ++k) {
@@ -715,19 +714,19 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         L.iter++; S.iterations++;
       }
       // poll the retired-slot counters one batch behind so the queue never drains
-      if (G == 2) { HIP_OK(hipEventRecord(s.grp_ev[3], s.stream2)); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[3], 0)); }
-      HIP_OK(hipMemcpyAsync(&s.pinned[(batch & 1) * 2], s.counters.p + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      for (int g = 1; g < G; ++g) { HIP_OK(hipEventRecord(s.grp_ev[g], s.gstream[g - 1])); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[g], 0)); }
+      HIP_OK(hipMemcpyAsync(&s.pinned[(batch & 1) * 4], s.counters.p + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_OK(hipEventRecord(s.poll_ev[batch & 1], st));
       if (batch > 0) {
         HIP_OK(hipEventSynchronize(s.poll_ev[(batch - 1) & 1]));
-        if (retired_all(&s.pinned[((batch - 1) & 1) * 2])) done = true;
+        if (retired_all(&s.pinned[((batch - 1) & 1) * 4])) done = true;
       }
       ++batch;
       if (S.iterations > max_iter) fail(LR_EDEVICE, "render loop did not terminate (internal error)");
     }
-    if (G == 2) HIP_OK(hipStreamSynchronize(s.stream2));
+    for (int g = 1; g < G; ++g) HIP_OK(hipStreamSynchronize(s.gstream[g - 1]));
     HIP_OK(hipStreamSynchronize(st));
-    if (!retired_all(&s.pinned[((batch - 1) & 1) * 2])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
+    if (!retired_all(&s.pinned[((batch - 1) & 1) * 4])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
   }
   if (n_pix > 0) {
     int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, n_pix);
@@ -833,7 +832,7 @@ int lr_scene_destroy(LrScene* s) {
   if (s->t_end) (void)hipEventDestroy(s->t_end);
   for (auto& p : s->pools) p.destroy();
   if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  for (auto& g : s->gstream) if (g) (void)hipStreamDestroy(g);
   for (auto& e : s->grp_ev) if (e) (void)hipEventDestroy(e);
   delete s;
   return LR_OK;

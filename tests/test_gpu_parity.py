@@ -644,3 +644,9 @@ def test_random_scenes_match_oracle(dev, oracle, first):
     for seed in range(first, first + 6):
         worst, n_prims, integ, cam, mean, nan = fz.run(seed, 40, 30, 16)
         assert worst < TOL, (seed, worst, n_prims, integ, cam)
+    if first == 0:
+        # seed 400649 of a 24 000-seed run in round 2: a Blinn-Phong sample whose pdf underflows to 0 makes the reference's
+        # recursion return 0 * c / 0 = NaN for the pixel whatever the rest of the path does; the throughput form has to
+        # poison the sample too (identical NaN masks are part of fz.run's check)
+        worst, n_prims, integ, cam, mean, nan = fz.run(400649, 40, 30, 8, 600)
+        assert worst < TOL and nan > 0, (worst, nan)

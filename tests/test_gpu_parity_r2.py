@@ -455,19 +455,22 @@ def test_round2_boundary_checks(dev):
     desc = load("cbox-spheres.toml", 32, 24)
     d = desc.desc
     lib = dev.lib()
-    # two parents for one node
+    # two parents for one node: the root's second child slot is pointed at a grandchild that node `a` already owns
     nodes = (abi.LrBvhNode * d.n_bvh_nodes)()
     C.memmove(nodes, d.bvh_nodes, C.sizeof(nodes))
-    inner = [(i, c) for i in range(d.n_bvh_nodes) for c in range(2) if nodes[i].child[c] >= 0]
-    assert len(inner) >= 2
-    (i0, c0), (i1, c1) = inner[0], inner[1]
-    nodes[i1].child[c1] = nodes[i0].child[c0] if nodes[i0].child[c0] > i1 else nodes[i1].child[c1]
-    if nodes[i1].child[c1] == nodes[i0].child[c0]:
-        bad = abi.LrSceneDesc.from_buffer_copy(d)
-        bad.bvh_nodes = C.cast(nodes, C.POINTER(abi.LrBvhNode))
-        h = C.c_void_p()
-        assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
-        assert b"two parents" in lib.lr_last_error() or b"parent" in lib.lr_last_error() or b"primitive" in lib.lr_last_error()
+    a, ca = next((i, nodes[i].child[c]) for i in range(1, d.n_bvh_nodes) for c in range(2) if nodes[i].child[c] >= 0)
+    assert ca > a >= 1
+    nodes[0].child[1] = ca
+    bad = abi.LrSceneDesc.from_buffer_copy(d)
+    bad.bvh_nodes = C.cast(nodes, C.POINTER(abi.LrBvhNode))
+    h = C.c_void_p()
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
+    assert b"two parents" in lib.lr_last_error()
+    # a node nobody references
+    C.memmove(nodes, d.bvh_nodes, C.sizeof(nodes))
+    leaf = next(nodes[i].child[c] for i in range(d.n_bvh_nodes) for c in range(2) if nodes[i].child[c] < 0)
+    nodes[a].child[0 if nodes[a].child[0] == ca else 1] = leaf
+    assert lib.lr_scene_create(0, C.byref(bad), C.byref(h)) == abi.LR_EINVAL
     scene = dev.Scene(desc)
     params = desc.render_params(spp=2, seed=1)
     # overlapping tiles
