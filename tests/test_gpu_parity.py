@@ -644,6 +644,15 @@ def test_random_scenes_match_oracle(dev, oracle, first):
     for seed in range(first, first + 6):
         worst, n_prims, integ, cam, mean, nan = fz.run(seed, 40, 30, 16)
         assert worst < TOL, (seed, worst, n_prims, integ, cam)
+    if first == 1000:
+        # hostile corners (non-integral and huge Phong exponents, roughness 0 and 3, ior 1 / 0 / 1e5, black and unit albedos,
+        # zero-area and needle quads, pin-head and planet spheres): equal non-finite masks, equal finite values
+        n_nan = 0
+        for seed in range(0, 12):
+            worst, n_prims, integ, cam, mean, nan = fz.run(seed, 40, 30, 8, 26, True)
+            assert worst < TOL, (seed, worst)
+            n_nan += nan > 0
+        assert n_nan >= 1                                 # the corners really produce lost samples
     if first == 0:
         # seed 400649 of a 24 000-seed run in round 2: a Blinn-Phong sample whose pdf underflows to 0 makes the reference's
         # recursion return 0 * c / 0 = NaN for the pixel whatever the rest of the path does; the throughput form has to
