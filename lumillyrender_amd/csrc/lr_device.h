@@ -83,10 +83,44 @@ struct DevParams {
   int integrator, spp; uint32_t seed; int depth, depth_limit, no_direct_emitter;
 };
 
+// A column of the path state.  Indexing yields a proxy whose load / store carry the non-temporal hint when the library
+// is built with -DLR_STATE_NT: the state (136 B x up to 32 M slots) streams through once per stage and should not evict
+// the BVH rows and shading records from L2.
+template <class T>
+struct StateArr {
+  T* p;
+  StateArr() = default;
+  __host__ __device__ StateArr(T* q) : p(q) {}
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+  __host__ __device__ StateArr& operator+=(size_t n) { p += n; return *this; }
+  __host__ __device__ StateArr operator+(size_t n) const { return StateArr(p + n); }
+  typedef float native_t __attribute__((ext_vector_type(sizeof(T) / 4)));
+  struct Ref {
+    T* q;
+    __device__ operator T() const {
+#ifdef LR_STATE_NT
+      native_t v = __builtin_nontemporal_load(reinterpret_cast<const native_t*>(q));
+      T r; __builtin_memcpy(&r, &v, sizeof(T)); return r;
+#else
+      return *q;
+#endif
+    }
+    __device__ void operator=(const T& v) const {
+#ifdef LR_STATE_NT
+      native_t n; __builtin_memcpy(&n, &v, sizeof(T));
+      __builtin_nontemporal_store(n, reinterpret_cast<native_t*>(q));
+#else
+      *q = v;
+#endif
+    }
+  };
+  __device__ Ref operator[](size_t i) const { return Ref{p + i}; }
+};
+
 struct DevState {
-  float4* ray_o; float4* ray_d; float2* hit;
-  float4* thr;   float4* rad;   float4* acc;
-  float4* sh_d;  float4* sh_w;
+  StateArr<float4> ray_o, ray_d; StateArr<float2> hit;
+  StateArr<float4> thr, rad, acc;
+  StateArr<float4> sh_d, sh_w;
   uint32_t* q_shade;                   // [queue][segment][kSeg] slot ids, written by k_trace
   uint32_t* c_shade;                   // [queue][segment] counts
   uint32_t* q_shadow;                  // [bsdf][segment][kSeg] slot ids with a pending shadow ray, written by k_shade<bsdf>
@@ -112,6 +146,7 @@ struct DevState {
   uint32_t pool_low, pool_batch;
   uint32_t trace_spb;                  // segments per k_trace workgroup pass: its per-BSDF lists span that many segments
   uint32_t shade_ordered;              // k_shade turns each list back into slot order in LDS before shading (coalesced state rows)
+  uint32_t dense_shade;                // k_shade_all shades the slots in place: k_trace writes no lists
   int stack_depth;                     // LDS traversal stack entries per lane
 };
 

@@ -962,11 +962,11 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           active = true;
           TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
           st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
-          qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
+          if (!st.dense_shade) qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
           n_rays += 1;
           if (COUNT) n_tst += r.tests;
         }
-        uint64_t todo = __ballot(active);
+        uint64_t todo = st.dense_shade ? 0ull : __ballot(active);
         while (todo) {
           int lead = (int)__builtin_ctzll(todo);
           int q = __shfl(qid, lead, 64);
@@ -1017,10 +1017,10 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           int key = -1;
           if (f) {
             st.hit[slot] = make_float2(tr.t, __int_as_float(tr.prim));
-            key = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
+            if (!st.dense_shade) key = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
             if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
           }
-          uint64_t todo = __ballot(f);
+          uint64_t todo = st.dense_shade ? 0ull : __ballot(f);     // k_shade_all walks the slots themselves: no lists
           while (todo) {
             int lead = (int)__builtin_ctzll(todo);
             int k = __shfl(key, lead, 64);
@@ -1095,11 +1095,15 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
 // `st` may point at global memory (streaming pipeline) or at LDS (resident pipeline).
 struct VertexOut { bool finished, has_shadow; V3 L; float g_term; uint32_t pixel, sample; bool sky_fetch; };
 
+// The rows a vertex reads: the slot's state and (for a hit) the primitive's shading record.  k_shade_all requests them for
+// all classes at once, ahead of the per-class code; the other callers load them where they always did.
+struct VertexIn { float4 ro, rd, th, ra; float2 h; float4 sh, m0, m1, m2; };
+
 template <int MT>
-LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot) {
+LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, const VertexIn& in) {
   VertexOut out; out.finished = false; out.has_shadow = false; out.sky_fetch = false;
   const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
-  float4 ro = st.ray_o[slot], rd = st.ray_d[slot], th = st.thr[slot], ra = st.rad[slot];
+  const float4 ro = in.ro, rd = in.rd, th = in.th, ra = in.ra;
   int depth = __float_as_int(ro.w);
   out.pixel = __float_as_uint(th.w); out.sample = __float_as_uint(ra.w);
   V3 o = v3(ro), d = v3(rd), T = v3(th);
@@ -1109,13 +1113,10 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
     out.sky_fetch = sc.sky_type == LR_SKY_IBL;
     out.finished = true;
   } else {
-    // resident pipeline: the hit record lives in the slot's (not yet written) shadow-weight row
-    float2 h = st.hit ? st.hit[slot] : make_float2(st.sh_w[slot].x, st.sh_w[slot].y);
-    float t = h.x; int prim = __float_as_int(h.y);
+    float t = in.h.x;
     V3 pos = o + d * t;                                            // triangle.rs:93 / sphere.rs:55
-    const float4* rec = sc.shade + 4 * (size_t)prim;              // one 64-B record: no dependent second fetch for the material
-    float4 sh = rec[0];
-    Mat m; m.m0 = rec[1]; m.m1 = rec[2]; m.m2 = rec[3];
+    float4 sh = in.sh;
+    Mat m; m.m0 = in.m0; m.m1 = in.m1; m.m2 = in.m2;
     uint32_t mw = __float_as_uint(sh.w);
     V3 nrm = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);        // sphere.rs:56 / triangle.rs:36
     V3 out_ = -d;
@@ -1167,6 +1168,20 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
   }
   out.L = L;
   return out;
+}
+
+template <int MT>
+LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot) {
+  VertexIn in;
+  in.ro = st.ray_o[slot]; in.rd = st.ray_d[slot]; in.th = st.thr[slot]; in.ra = st.rad[slot];
+  in.h = make_float2(0.0f, 0.0f); in.sh = in.m0 = in.m1 = in.m2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (MT != kQMiss) {
+    // resident pipeline: the hit record lives in the slot's (not yet written) shadow-weight row
+    if (st.hit) in.h = st.hit[slot]; else { float4 w = st.sh_w[slot]; in.h = make_float2(w.x, w.y); }
+    const float4* rec = sc.shade + 4 * (size_t)__float_as_int(in.h.y);   // one 64-B record: no dependent second fetch for the material
+    in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
+  }
+  return shade_vertex_core<MT>(sc, st, rp, slot, in);
 }
 
 // The shadow stage for one slot (scene.rs:127-147): adds the direct-light term if the sampled point is visible.
@@ -1264,6 +1279,78 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
   }
   stat_accumulate(&s_stat[ST_SAMPLES], n_done);
   if (MT == kQMiss) stat_accumulate(&s_stat[ST_SKY], n_sky);
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
+}
+
+// Dense shading: ONE launch per iteration walks the slots themselves, 64 consecutive slots per wave, and runs the vertex
+// code of every class (BSDF or miss) present among them under its lane mask.  The per-class lists of k_shade keep the
+// lanes of a wave on one code path, but a wave then touches the 16-B state rows of 64 slots spread over 64 / density
+// consecutive ones: a class that holds a quarter of the slots (the misses of an open scene) moves four times the bytes
+// it needs, and every line is read and written once per class that has a slot in it.  The stage is bandwidth-bound and
+// has VALU time to spare, so it pays divergence instead: every state line is fetched once and written back once.
+// MASK = the BSDF types that can occur (a scene's materials); bit kQMiss is implied.
+#ifndef LR_DENSE_WAVES
+#define LR_DENSE_WAVES 4
+#endif
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene sc, DevState st, DevParams rp) {
+  __shared__ PoolLds pl;
+  __shared__ uint32_t s_shadow, s_retired;
+  __shared__ uint32_t s_stat[ST_COUNT];
+  if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
+  uint32_t n_done = 0, n_sky = 0;
+  const uint32_t n_ranges = (st.n_seg + st.trace_spb - 1) / st.trace_spb;
+  for (uint32_t g = blockIdx.x; g < n_ranges; g += gridDim.x) {
+    const uint32_t g0 = g * st.trace_spb;
+    const uint32_t nsegs = st.n_seg - g0 < st.trace_spb ? st.n_seg - g0 : st.trace_spb;
+    const uint32_t n = nsegs * kSeg, slot0 = g0 * kSeg;
+    uint32_t* shadow_q = st.q_shadow + (size_t)g0 * kSeg;          // one shadow list per range (list 0's storage; k_shadow gets mt_mask = 1)
+    const uint32_t batch = n / 4 < (uint32_t)kSeg ? (uint32_t)kSeg : (n / 4 > 8192u ? 8192u : n / 4);
+    if (threadIdx.x == 0) { pool_begin(st, g0, n < batch ? n : batch, &pl, false, batch); s_shadow = 0; s_retired = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kBlock) {
+      const uint32_t slot = slot0 + base + threadIdx.x;           // n is a multiple of kBlock: every lane has a slot
+      // two round trips per slot: every state row at once, then the shading record of the primitive that was hit
+      VertexIn in;
+      in.h = st.hit[slot];
+      in.ro = st.ray_o[slot]; in.rd = st.ray_d[slot]; in.th = st.thr[slot]; in.ra = st.rad[slot];
+      float4 acc_row = st.acc[slot];
+      int key = -1;
+      in.sh = in.m0 = in.m1 = in.m2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (__float_as_int(in.ro.w) >= 0) {
+        int prim = __float_as_int(in.h.y);
+        key = kQMiss;
+        if (prim >= 0) {
+          const float4* rec = sc.shade + 4 * (size_t)prim;
+          in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
+          key = (int)__float_as_uint(in.m0.w);                      // {color.rgb, type bits}: the record names its own class
+        }
+      }
+      VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
+      if ((MASK & 1u) && __ballot(key == 0)) { if (key == 0) v = shade_vertex_core<0>(sc, st, rp, slot, in); }
+      if ((MASK & 2u) && __ballot(key == 1)) { if (key == 1) v = shade_vertex_core<1>(sc, st, rp, slot, in); }
+      if ((MASK & 4u) && __ballot(key == 2)) { if (key == 2) v = shade_vertex_core<2>(sc, st, rp, slot, in); }
+      if ((MASK & 8u) && __ballot(key == 3)) { if (key == 3) v = shade_vertex_core<3>(sc, st, rp, slot, in); }
+      if ((MASK & 16u) && __ballot(key == 4)) { if (key == 4) v = shade_vertex_core<4>(sc, st, rp, slot, in); }
+      if (__ballot(key == kQMiss)) { if (key == kQMiss) v = shade_vertex_core<kQMiss>(sc, st, rp, slot, in); }
+      if (v.finished) n_done += 1;
+      if (v.sky_fetch) n_sky += 1;
+      bool r = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample, &acc_row);
+      (void)wave_reserve(&s_retired, r);
+      uint32_t idx = wave_reserve(&s_shadow, v.has_shadow);
+      if (v.has_shadow) shadow_q[idx] = slot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      st.c_shadow[g0] = s_shadow;
+      pool_end(st, g0, &pl);
+      if (s_retired) atomicAdd(st.n_retired, s_retired);
+    }
+    __syncthreads();
+  }
+  stat_accumulate(&s_stat[ST_SAMPLES], n_done);
+  stat_accumulate(&s_stat[ST_SKY], n_sky);
   __syncthreads();
   stat_flush(st.stats, s_stat);
 }

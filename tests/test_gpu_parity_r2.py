@@ -423,18 +423,21 @@ def test_two_rank_bench_assembles_the_single_rank_film(tmp_path):
 # ---- switches that must not change a film; boundary checks added in round 2 ----------------------------------------
 
 def test_sorted_and_unordered_variants_are_bit_identical(dev, monkeypatch):
-    """LR_SORT=1 (rays binned by octant / origin cell before trace and shadow) and LR_SHADE_ORDER=0 (shade in list order)
-    only change which lane handles which ray or vertex: same films, same counters, on the mesh scenes where they apply."""
+    """LR_DENSE=0 (per-class lists + one k_shade launch per class instead of k_shade_all over the slots), LR_SORT=1 (rays
+    binned by octant / origin cell before trace and shadow), LR_SHADE_ORDER=0 (lists shaded in list order) and the number
+    of slot groups only change which lane handles which ray or vertex: same films, same counters."""
     if not _generated_assets():
         pytest.skip("generated assets missing")
     from lumillyrender_amd import abi
-    for name, spp in (("mesh-box.toml", 24), ("ibl-lens.toml", 16)):
+    for name, spp in (("mesh-box.toml", 24), ("ibl-lens.toml", 16), ("brdf-row.toml", 16)):
         desc = load(name, 160, 120)                     # 19200 pixels: several ranges, so the sort window is exercised with real lists
         scene = dev.Scene(desc)
         p = desc.render_params(spp=spp, seed=41, flags=abi.LR_FLAG_STREAMING)
         base = scene.render(p)
         st0 = scene.stats()
-        for env in ({"LR_SORT": "1"}, {"LR_SHADE_ORDER": "0"}, {"LR_SORT": "1", "LR_SHADE_ORDER": "0", "LR_MAXGROUP": "2"}, {"LR_GROUPS": "1"}):
+        for env in ({"LR_DENSE": "0"}, {"LR_SORT": "1"}, {"LR_DENSE": "0", "LR_SORT": "1"}, {"LR_DENSE": "0", "LR_SHADE_ORDER": "0"},
+                    {"LR_DENSE": "0", "LR_SORT": "1", "LR_SHADE_ORDER": "0", "LR_MAXGROUP": "2"}, {"LR_GROUPS": "1"}, {"LR_GROUPS": "3"},
+                    {"LR_DENSE": "0", "LR_GROUPS": "1"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             img = scene.render(p)

@@ -28,7 +28,7 @@ print('%8.1f Msamples/s  iters %4d  trace %.3f shade %.3f shadow %.3f ms/launch'
 import json
 d=json.load(open("$OUT/pmc_$label.json"))["kernels"]
 for k,v in d.items():
-    if not (k.startswith("k_trace") or k.startswith("k_shade<0") or k.startswith("k_shadow")): continue
+    if not (k.startswith("k_trace") or k.startswith("k_shade") or k.startswith("k_shadow")): continue
     g=lambda n: v.get(n,0.0)
     print("   $label %-22s us %8.1f  VALU %.2e lanes/instr %4.1f  wait %.2f  VMEM_RD %.2e  TCP acc %.2e -> TCC rd %.2e  TCC req %.2e hit %.2f  FETCH %.1f MB"%(k[:22], g("avg_us_in_pmc_pass"), g("SQ_INSTS_VALU"), g("SQ_THREAD_CYCLES_VALU")/max(g("SQ_INSTS_VALU"),1), g("SQ_WAIT_ANY")/max(g("SQ_WAVE_CYCLES"),1), g("SQ_INSTS_VMEM_RD"), g("TCP_TOTAL_CACHE_ACCESSES"), g("TCP_TCC_READ_REQ"), g("TCC_REQ"), g("TCC_HIT")/max(g("TCC_REQ"),1), g("FETCH_SIZE")*2*1024/1e6))
 PY
