@@ -133,13 +133,18 @@ LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
 
 // (stack entries carry no entry distance: a stale subtree costs one node fetch whose boxes then fail
 //  the cull test, but 4 B per entry instead of 8 doubles the workgroups an LDS-bound CU can hold)
+// The two homes of a stack entry are addressed through pointers of their own address spaces: with generic pointers the
+// compiler folds the branches into one FLAT load of a selected address, and every pop then takes the flat path to LDS
+// (longer than ds_read and it waits for all outstanding vector-memory loads as well).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
 LR_DEV void stack_store(const DevScene& sc, uint32_t* stk_n, int e, uint32_t v) {
-  if (e < sc.stack_lds) stk_n[e * kBlock + threadIdx.x] = v;
-  else sc.stack_spill[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x] = v;
+  if (e < sc.stack_lds) ((lds_u32*)stk_n)[e * kBlock + threadIdx.x] = v;
+  else ((glb_u32*)sc.stack_spill)[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x] = v;
 }
 LR_DEV uint32_t stack_load(const DevScene& sc, const uint32_t* stk_n, int e) {
-  if (e < sc.stack_lds) return stk_n[e * kBlock + threadIdx.x];
-  return sc.stack_spill[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x];
+  if (e < sc.stack_lds) return ((const lds_u32*)stk_n)[e * kBlock + threadIdx.x];
+  return ((const glb_u32*)sc.stack_spill)[((size_t)blockIdx.x * sc.spill_depth + (e - sc.stack_lds)) * kBlock + threadIdx.x];
 }
 template <bool SHADOW>
 LR_DEV bool trav_pop(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n) {
@@ -181,15 +186,21 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = __builtin_fmaf(g.x, s.ix, s.ox);
     const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = __builtin_fmaf(g.y, s.iy, s.oy);
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = __builtin_fmaf(g.z, s.iz, s.oz);
-    const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
-    const uint32_t hx = __float_as_uint(qa.w), hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
+    // t(q) is monotonic in q with the sign of 1/d: the ray enters a slab through the lower plane when it travels up the
+    // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
+    const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
+    const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
+    const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
+    const uint32_t nx = upx ? wlx : whx, fx = upx ? whx : wlx;
+    const uint32_t ny = upy ? wly : why, fy = upy ? why : wly;
+    const uint32_t nz = upz ? wlz : whz, fz = upz ? whz : wlz;
 #define LR_SLAB(K, C, R)                                                                                         \
     {                                                                                                            \
-      float a0 = __builtin_fmaf(qbyte(lx, C), ax, bx), a1 = __builtin_fmaf(qbyte(hx, C), ax, bx);                \
-      float b0 = __builtin_fmaf(qbyte(ly, C), ay, by), b1 = __builtin_fmaf(qbyte(hy, C), ay, by);                \
-      float c0 = __builtin_fmaf(qbyte(lz, C), az, bz), c1 = __builtin_fmaf(qbyte(hz, C), az, bz);                \
-      float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, a1), __builtin_fminf(b0, b1)), __builtin_fmaxf(__builtin_fminf(c0, c1), 0.0f)); \
-      float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(b0, b1)), __builtin_fminf(__builtin_fmaxf(c0, c1), s.cull)); \
+      float a0 = __builtin_fmaf(qbyte(nx, C), ax, bx), a1 = __builtin_fmaf(qbyte(fx, C), ax, bx);                \
+      float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
+      float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
+      float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
+      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, s.cull));                          \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
     LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)
