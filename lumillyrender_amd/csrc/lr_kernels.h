@@ -615,6 +615,39 @@ LR_DEV V3 material_coef(const Mat& m, V3 out_, V3 n, float fly_distance) {   // 
   return v3(1.0f, 1.0f, 1.0f);
 }
 
+// Per-lane BSDF type inside one wave (k_shade_all on a scene with several BSDFs): each type present among the active
+// lanes runs under its own lane mask, so the code AROUND the material calls -- emission, roulette, the light sample, both
+// RNG blocks, the stores -- is executed once for all hit lanes instead of once per type.  Same functions, same inputs.
+constexpr int kMtDyn = 8;
+#define LR_MT_CASES(CALL)                                                          \
+  if ((MASK & 1u) && __ballot(mt == 0)) { if (mt == 0) { CALL(0) } }                \
+  if ((MASK & 2u) && __ballot(mt == 1)) { if (mt == 1) { CALL(1) } }                \
+  if ((MASK & 4u) && __ballot(mt == 2)) { if (mt == 2) { CALL(2) } }                \
+  if ((MASK & 8u) && __ballot(mt == 3)) { if (mt == 3) { CALL(3) } }                \
+  if ((MASK & 16u) && __ballot(mt == 4)) { if (mt == 4) { CALL(4) } }
+template <uint32_t MASK>
+LR_DEV V3 material_brdf_dyn(int mt, const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
+  V3 r = v3(0.0f, 0.0f, 0.0f);
+#define LR_CALL(K) r = material_brdf<K>(m, out_, in_, n, pos);
+  LR_MT_CASES(LR_CALL)
+#undef LR_CALL
+  return r;
+}
+template <uint32_t MASK>
+LR_DEV void material_sample_dyn(int mt, const Mat& m, V3 out_, V3 n, const float* xi, V3* in_out, float* pdf_out) {
+#define LR_CALL(K) material_sample<K>(m, out_, n, xi, in_out, pdf_out);
+  LR_MT_CASES(LR_CALL)
+#undef LR_CALL
+}
+template <uint32_t MASK>
+LR_DEV V3 material_coef_dyn(int mt, const Mat& m, V3 out_, V3 n, float fly_distance) {
+  V3 r = v3(1.0f, 1.0f, 1.0f);
+#define LR_CALL(K) r = material_coef<K>(m, out_, n, fly_distance);
+  LR_MT_CASES(LR_CALL)
+#undef LR_CALL
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // cameras  (camera.rs)
 // ------------------------------------------------------------------------------------------
@@ -1110,8 +1143,9 @@ struct VertexOut { bool finished, has_shadow; V3 L; float g_term; uint32_t pixel
 // all classes at once, ahead of the per-class code; the other callers load them where they always did.
 struct VertexIn { float4 ro, rd, th, ra; float2 h; float4 sh, m0, m1, m2; };
 
-template <int MT>
-LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, const VertexIn& in) {
+// MT = the BSDF type, kQMiss, or kMtDyn: type per lane (`mt`, one of MASK's bits), see material_*_dyn
+template <int MT, uint32_t MASK = 0>
+LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, const VertexIn& in, int mt = MT) {
   VertexOut out; out.finished = false; out.has_shadow = false; out.sky_fetch = false;
   const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
   const float4 ro = in.ro, rd = in.rd, th = in.th, ra = in.ra;
@@ -1155,7 +1189,9 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const
         V3 point_normal = orienting_normal(out_, nrm);
         float point_cos = dot(dir, point_normal);
         if (point_cos > 0.0f) {
-          V3 brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
+          V3 brdf;
+          if constexpr (MT == kMtDyn) brdf = material_brdf_dyn<MASK>(mt, m, out_, dir, point_normal, pos);
+          else brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
           V3 W = T * (brdf * (point_cos * rcp_r(d2 * lpdf * p)));
           st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
           st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
@@ -1165,9 +1201,16 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const
       // ---- BSDF sample (scene.rs:78-102) ----
       Draw4 d2r = rng_block(rp.seed, out.pixel, out.sample, 2u + 2u * (uint32_t)depth);
       V3 in_; float pdf;
-      material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
-      V3 brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
-      V3 coef = material_coef<MT>(m, out_, nrm, t);
+      V3 brdf, coef;
+      if constexpr (MT == kMtDyn) {
+        material_sample_dyn<MASK>(mt, m, out_, nrm, d2r.v, &in_, &pdf);
+        brdf = material_brdf_dyn<MASK>(mt, m, out_, in_, nrm, pos);
+        coef = material_coef_dyn<MASK>(mt, m, out_, nrm, t);
+      } else {
+        material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
+        brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
+        coef = material_coef<MT>(m, out_, nrm, t);
+      }
       float c = dot(in_, nrm);
       V3 f = brdf * coef * (c * rcp_r(pdf * p));
       T = T * f;
@@ -1339,11 +1382,12 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
         }
       }
       VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
-      if ((MASK & 1u) && __ballot(key == 0)) { if (key == 0) v = shade_vertex_core<0>(sc, st, rp, slot, in); }
-      if ((MASK & 2u) && __ballot(key == 1)) { if (key == 1) v = shade_vertex_core<1>(sc, st, rp, slot, in); }
-      if ((MASK & 4u) && __ballot(key == 2)) { if (key == 2) v = shade_vertex_core<2>(sc, st, rp, slot, in); }
-      if ((MASK & 8u) && __ballot(key == 3)) { if (key == 3) v = shade_vertex_core<3>(sc, st, rp, slot, in); }
-      if ((MASK & 16u) && __ballot(key == 4)) { if (key == 4) v = shade_vertex_core<4>(sc, st, rp, slot, in); }
+      if constexpr ((MASK & (MASK - 1u)) == 0u) {                    // one BSDF in the scene: its code, statically
+        constexpr int K = MASK == 1u ? 0 : (MASK == 2u ? 1 : (MASK == 4u ? 2 : (MASK == 8u ? 3 : 4)));
+        if (key == K) v = shade_vertex_core<K>(sc, st, rp, slot, in);
+      } else {
+        if (key >= 0 && key < kQMiss) v = shade_vertex_core<kMtDyn, MASK>(sc, st, rp, slot, in, key);
+      }
       if (__ballot(key == kQMiss)) { if (key == kQMiss) v = shade_vertex_core<kQMiss>(sc, st, rp, slot, in); }
       if (v.finished) n_done += 1;
       if (v.sky_fetch) n_sky += 1;
