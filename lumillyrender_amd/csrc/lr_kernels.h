@@ -110,6 +110,9 @@ struct Trav {
   int prim, cur, sp;
   bool occluded;
   uint32_t visits, tests;
+#ifdef LR_DIAG
+  uint32_t last_wait;               // cycles the last node / leaf step spent between issuing its fetch and having the rows
+#endif
 };
 
 template <bool SHADOW>
@@ -174,6 +177,9 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
   //  nodes were L1 hits already; the step is bound by its ~150 dependent VALU instructions, not by the fetch.)
   const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
   float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
+#ifdef LR_DIAG
+  { unsigned long long w0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); s.last_wait = (uint32_t)(__builtin_amdgcn_s_memtime() - w0); }
+#endif
   s.visits += 4;
   float k0, k1, k2, k3;
   int r0 = __float_as_int(rc.x), r1 = __float_as_int(rc.y), r2 = __float_as_int(rc.z), r3 = __float_as_int(rc.w);
@@ -226,6 +232,9 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
   // fetch round trip plus n tests, not n round trips
   const float4* q = sc.prims + 3 * (size_t)first;
   float4 n0 = q[0], n1 = q[1], n2 = q[2];
+#ifdef LR_DIAG
+  { unsigned long long w0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); s.last_wait = (uint32_t)(__builtin_amdgcn_s_memtime() - w0); }
+#endif
   for (uint32_t k = 0; k < count; ++k) {
     float4 q0 = n0, q1 = n1, q2 = n2;
     if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
@@ -254,7 +263,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
 #endif
 constexpr int kDescendBurst = LR_DESCEND_BURST;
 // LR_DIAG build (make diag): wave-uniform step / lane / cycle counters of the traversal loop, printed by lr_render
-struct TravDiag { unsigned long long node_steps, node_lanes, leaf_steps, leaf_lanes, leaf_prims_max, leaf_prims, cyc_node, cyc_leaf, cyc_retire, cyc_fetch, cyc_total, rays; };
+struct TravDiag { unsigned long long node_steps, node_lanes, leaf_steps, leaf_lanes, leaf_prims_max, leaf_prims, cyc_node, cyc_leaf, cyc_retire, cyc_fetch, cyc_total, rays, cyc_node_wait, cyc_leaf_wait; };
 #ifdef LR_DIAG
 #define LR_DIAG_ONLY(...) __VA_ARGS__
 #else
@@ -271,6 +280,7 @@ LR_DEV void trav_burst(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, boo
     LR_DIAG_ONLY(unsigned long long t0 = __builtin_amdgcn_s_memtime();)
     if (nm) go = trav_node<SHADOW>(sc, s, stk_n);
     LR_DIAG_ONLY(dg->node_steps += 1; dg->node_lanes += (unsigned)__builtin_popcountll(bm); dg->cyc_node += __builtin_amdgcn_s_memtime() - t0;)
+    LR_DIAG_ONLY(dg->cyc_node_wait += (unsigned)__shfl((int)s.last_wait, (int)__builtin_ctzll(bm), 64);)
   }
 #ifdef LR_DIAG
   {
@@ -284,8 +294,9 @@ LR_DEV void trav_burst(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n, boo
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
+  LR_DIAG_ONLY(uint64_t blw = __ballot(go && s.cur < 0);)
   if (go && s.cur < 0) go = trav_leaf<SHADOW>(sc, s, stk_n);
-  LR_DIAG_ONLY(dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1;)
+  LR_DIAG_ONLY(dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; if (blw) dg->cyc_leaf_wait += (unsigned)__shfl((int)s.last_wait, (int)__builtin_ctzll(blw), 64);)
 }
 
 template <bool SHADOW>

@@ -770,10 +770,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     TravDiag d;
     HIP_OK(hipMemcpy(&d, s.stats_dev.p + (size_t)kStatShards * kStatStride + 8, sizeof(d), hipMemcpyDeviceToHost));
     if (d.node_steps) std::fprintf(stderr, "[LR_DIAG] k_trace waves: node steps %llu (%.1f lanes), leaf steps %llu (%.1f lanes, %.2f prims/lane, max %.2f/step); "
-        "wave cycles: node %.1f%% leaf %.1f%% retire %.1f%% fetch %.1f%% other %.1f%%; per ray: %.2f node-lane-steps %.2f leaf-lane-steps\n",
+        "wave cycles: node %.1f%% (%.1f%% waiting for its rows, %.0f cycles per step of %.0f) leaf %.1f%% (%.1f%% waiting for the first rows, %.0f of %.0f) retire %.1f%% fetch %.1f%% other %.1f%%; per ray: %.2f node-lane-steps %.2f leaf-lane-steps\n",
         d.node_steps, (double)d.node_lanes / d.node_steps, d.leaf_steps, (double)d.leaf_lanes / std::max<unsigned long long>(d.leaf_steps, 1), (double)d.leaf_prims / std::max<unsigned long long>(d.leaf_lanes, 1),
         (double)d.leaf_prims_max / std::max<unsigned long long>(d.leaf_steps, 1),
-        100.0 * d.cyc_node / d.cyc_total, 100.0 * d.cyc_leaf / d.cyc_total, 100.0 * d.cyc_retire / d.cyc_total, 100.0 * d.cyc_fetch / d.cyc_total,
+        100.0 * d.cyc_node / d.cyc_total, 100.0 * d.cyc_node_wait / d.cyc_total, (double)d.cyc_node_wait / d.node_steps, (double)d.cyc_node / d.node_steps,
+        100.0 * d.cyc_leaf / d.cyc_total, 100.0 * d.cyc_leaf_wait / d.cyc_total, (double)d.cyc_leaf_wait / std::max<unsigned long long>(d.leaf_steps, 1), (double)d.cyc_leaf / std::max<unsigned long long>(d.leaf_steps, 1),
+        100.0 * d.cyc_retire / d.cyc_total, 100.0 * d.cyc_fetch / d.cyc_total,
         100.0 * (double)(d.cyc_total - d.cyc_node - d.cyc_leaf - d.cyc_retire - d.cyc_fetch) / d.cyc_total,
         (double)d.node_lanes / std::max<unsigned long long>(d.rays, 1), (double)d.leaf_lanes / std::max<unsigned long long>(d.rays, 1));
   }
