@@ -705,9 +705,9 @@ LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* 
 // ------------------------------------------------------------------------------------------
 // sky  (sky.rs)
 // ------------------------------------------------------------------------------------------
-LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
-  if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
-  float theta = det_acos(dir.y);                                       // sky.rs:57-78
+// IBL: the texel a direction looks up (sky.rs:57-78)
+LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
+  float theta = det_acos(dir.y);
   float phi = det_atan2(dir.z, dir.x);
   float uu = (phi + kPi + sc.sky_lon) / (2.0f * kPi);
   float u = uu >= 0.0f ? det_fmod_pos(uu, 1.0f) : -det_fmod_pos(-uu, 1.0f);
@@ -717,8 +717,11 @@ LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
   uint64_t all = (uint64_t)width * height;
   float fx = __builtin_floorf((float)width * u), fy = __builtin_floorf((float)height * v);
   uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates
-  uint64_t index = (y * width + x) % all;
-  return v3(sc.texels[index]);
+  return (y * width + x) % all;
+}
+LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
+  if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
+  return v3(sc.texels[sky_texel_index(sc, dir)]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1165,7 +1168,8 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const
   V3 o = v3(ro), d = v3(rd), T = v3(th);
   V3 L = v3(ra); out.g_term = rd.w;
   if (MT == kQMiss) {                                              // scene.rs:29 / :43
-    L = L + T * sky_radiance(sc, d);
+    // k_shade_all requests the IBL texel of a miss together with the shading records of the hits (mt = 1: it is in in.sh)
+    L = L + T * (mt == 1 ? v3(in.sh) : sky_radiance(sc, d));
     out.sky_fetch = sc.sky_type == LR_SKY_IBL;
     out.finished = true;
   } else {
@@ -1355,8 +1359,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 // it needs, and every line is read and written once per class that has a slot in it.  The stage is bandwidth-bound and
 // has VALU time to spare, so it pays divergence instead: every state line is fetched once and written back once.
 // MASK = the BSDF types that can occur (a scene's materials); bit kQMiss is implied.
+// 5 waves per SIMD = 96 VGPRs (32-96 B of scratch): not for this kernel's own occupancy but for what fits BESIDE it -- one
+// of its waves leaves room for five 80-VGPR traversal waves of another slot group on the same SIMD, two for four.  At 4 waves
+// the allocation follows the code (112 or 120 registers) and a 4-register change cost the mesh scene 8 %.
 #ifndef LR_DENSE_WAVES
-#define LR_DENSE_WAVES 4
+#define LR_DENSE_WAVES 5
 #endif
 template <uint32_t MASK>
 __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene sc, DevState st, DevParams rp) {
@@ -1366,6 +1373,7 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
   if (threadIdx.x < ST_COUNT) s_stat[threadIdx.x] = 0;
   uint32_t n_done = 0, n_sky = 0;
   const uint32_t n_ranges = (st.n_seg + st.trace_spb - 1) / st.trace_spb;
+  const bool ibl = sc.sky_type == LR_SKY_IBL;
   for (uint32_t g = blockIdx.x; g < n_ranges; g += gridDim.x) {
     const uint32_t g0 = g * st.trace_spb;
     const uint32_t nsegs = st.n_seg - g0 < st.trace_spb ? st.n_seg - g0 : st.trace_spb;
@@ -1390,6 +1398,8 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
           const float4* rec = sc.shade + 4 * (size_t)prim;
           in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
           key = (int)__float_as_uint(in.m0.w);                      // {color.rgb, type bits}: the record names its own class
+        } else if (ibl) {
+          in.sh = sc.texels[sky_texel_index(sc, v3(in.rd))];        // same round trip as the records of the hit lanes
         }
       }
       VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
@@ -1399,7 +1409,7 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
       } else {
         if (key >= 0 && key < kQMiss) v = shade_vertex_core<kMtDyn, MASK>(sc, st, rp, slot, in, key);
       }
-      if (__ballot(key == kQMiss)) { if (key == kQMiss) v = shade_vertex_core<kQMiss>(sc, st, rp, slot, in); }
+      if (__ballot(key == kQMiss)) { if (key == kQMiss) v = shade_vertex_core<kQMiss>(sc, st, rp, slot, in, ibl ? 1 : 0); }
       if (v.finished) n_done += 1;
       if (v.sky_fetch) n_sky += 1;
       bool r = finish_and_regenerate(sc, st, rp, &pl, slot, v.finished, false, v.L, v.g_term, v.pixel, v.sample, &acc_row);
