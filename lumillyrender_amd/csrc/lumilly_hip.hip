@@ -536,8 +536,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   hipStream_t st = s.stream;
   s.ray_o.ensure(n_slots); s.ray_d.ensure(n_slots); s.hit.ensure(n_slots); s.thr.ensure(n_slots); s.rad.ensure(n_slots);
   s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
-  s.q_shade.ensure((size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
-  s.q_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
+  // dense shading (k_shade_all): one launch per iteration over the slots themselves instead of one per class over lists;
+  // then k_trace writes no lists and there is ONE shadow list per range (4 B per slot instead of 44)
+  const bool dense_shade = !resident && !(std::getenv("LR_DENSE") && std::atoi(std::getenv("LR_DENSE")) == 0);
+  const size_t shadow_lists = dense_shade ? 1 : (size_t)(kNumShadeQueues - 1);
+  s.q_shade.ensure(dense_shade ? 1 : (size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
+  s.q_shadow.ensure(shadow_lists * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
   s.pool.ensure(n_seg);
   // Ray sort before trace / shadow (lr_kernels.h "Ray sort"): measured on the 100k-triangle configs it LOSES 6 % (lanes per
   // VALU instruction 20.9 -> 23.0, but HBM fetch x3 and L2 hit rate 0.67 -> 0.54: the sorted order gathers 16-B rows from all
@@ -566,8 +570,6 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const bool shade_ordered = !resident && !(std::getenv("LR_SHADE_ORDER") && std::atoi(std::getenv("LR_SHADE_ORDER")) == 0);
   ds.shade_ordered = shade_ordered ? 1u : 0u;
   const size_t shade_lds = shade_ordered ? sizeof(ShadeOrderLds) : 0;
-  // dense shading (k_shade_all): one launch per iteration over the slots themselves instead of one per class over lists
-  const bool dense_shade = !resident && !(std::getenv("LR_DENSE") && std::atoi(std::getenv("LR_DENSE")) == 0);
   ds.dense_shade = dense_shade ? 1u : 0u;
   ds.next_item = s.counters.p; ds.n_retired = s.counters.p + 1;
   if (want_packed) s.packed.ensure((size_t)std::max<uint32_t>(n_pix, 1) * 3);
@@ -653,8 +655,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       q.ds = ds;
       q.ds.ray_o += base; q.ds.ray_d += base; q.ds.hit += base; q.ds.thr += base; q.ds.rad += base; q.ds.acc += base;
       q.ds.sh_d += base; q.ds.sh_w += base;
-      q.ds.q_shade += (size_t)kNumShadeQueues * base; q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
-      q.ds.q_shadow += (size_t)(kNumShadeQueues - 1) * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
+      if (!dense_shade) q.ds.q_shade += (size_t)kNumShadeQueues * base;
+      q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
+      q.ds.q_shadow += shadow_lists * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
       q.ds.pool += base_seg;
       if (q.ds.order) { q.ds.order += base; q.ds.sort_key += base; }
       q.ds.n_retired = s.counters.p + 1 + g;
