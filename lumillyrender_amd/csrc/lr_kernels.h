@@ -105,7 +105,7 @@ struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; }
 template <bool SHADOW>
 struct Trav {
   V3 o, d;
-  float ix, iy, iz, ox, oy, oz;
+  float ix, iy, iz;
   float cull, dist, t;
   int prim, cur, sp;
   bool occluded;
@@ -130,7 +130,6 @@ LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
     float dy = __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y;
     float dz = __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z;
     s.ix = __builtin_amdgcn_rcpf(dx); s.iy = __builtin_amdgcn_rcpf(dy); s.iz = __builtin_amdgcn_rcpf(dz);
-    s.ox = -o.x * s.ix; s.oy = -o.y * s.iy; s.oz = -o.z * s.iz;
   }
 }
 
@@ -189,9 +188,9 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     const uint32_t eb = __float_as_uint(g.w);
     // step * 1/d is exact (a power of two times a float); the offset costs two roundings of magnitude |o| ulp, far inside
     // the padding the boxes carry
-    const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = __builtin_fmaf(g.x, s.ix, s.ox);
-    const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = __builtin_fmaf(g.y, s.iy, s.oy);
-    const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = __builtin_fmaf(g.z, s.iz, s.oz);
+    const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - s.o.x) * s.ix;
+    const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - s.o.y) * s.iy;
+    const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - s.o.z) * s.iz;
     // t(q) is monotonic in q with the sign of 1/d: the ray enters a slab through the lower plane when it travels up the
     // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
@@ -206,7 +205,7 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
       float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
       float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
       float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
-      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, s.cull));                          \
+      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, SHADOW ? s.cull : s.t));            \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
     LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)
@@ -250,7 +249,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
       if (diff < -kEps) { s.occluded = true; return false; }
       if (diff > kEps) continue;
     }
-    if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; s.cull = t; }
+    if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }   // closest-hit queries prune with s.t itself
   }
   return trav_pop<SHADOW>(sc, s, stk_n);
 }
@@ -987,6 +986,9 @@ static_assert(kSortBins == 2 * kBlock, "sort_scan gives two bins to each thread"
 #ifndef LR_TRACE_WAVES
 #define LR_TRACE_WAVES 6
 #endif
+#ifndef LR_SHADOW_WAVES
+#define LR_SHADOW_WAVES 6
+#endif
 constexpr int kMaxGroup = 32;            // segments a workgroup may own at once (16 K rays per pass: long passes amortise the run-down of the last rays)
 #ifndef LR_REFILL_BELOW
 #define LR_REFILL_BELOW 32
@@ -1021,9 +1023,9 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
           st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
           if (!st.dense_shade) qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
-          n_rays += 1;
           if (COUNT) n_tst += r.tests;
         }
+        n_rays += (uint32_t)__builtin_popcountll(__ballot(active));
         uint64_t todo = st.dense_shade ? 0ull : __ballot(active);
         while (todo) {
           int lead = (int)__builtin_ctzll(todo);
@@ -1100,19 +1102,22 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
             slot = slot0 + local;
             float4 ro = st.ray_o[slot], rd = st.ray_d[slot];         // every entry of the order is a live ray
             trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
-            has = true; n_rays += 1;
+            has = true;
           }
+          n_rays += (uint32_t)__builtin_popcountll(__ballot(got));   // counted per wave (a scalar), not per lane
         } else {
           uint32_t idx = wave_reserve(&s_next, need);
           exhausted = __ballot(need && idx >= total) != 0;           // the dispenser is monotonic: one lane past the end = empty for all
+          bool started = false;
           if (need && idx < total) {
             slot = slot0 + idx;
             float4 ro = st.ray_o[slot], rd = st.ray_d[slot];         // both rows in one round trip (a retired slot costs a wasted 16 B, only at the end of a render)
             if (__float_as_int(ro.w) >= 0) {
               trav_begin<false>(tr, v3(ro), v3(rd), 0.0f);
-              has = true; n_rays += 1;
+              has = true; started = true;
             }
           }
+          n_rays += (uint32_t)__builtin_popcountll(__ballot(started));   // counted per wave (a scalar), not per lane
         }
         LR_DIAG_ONLY(dg.cyc_fetch += __builtin_amdgcn_s_memtime() - tq;)
         if (__ballot(has) == 0) { if (exhausted) break; continue; }
@@ -1128,7 +1133,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
       }
 #ifdef LR_DIAG
       dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
-      { uint32_t r = n_rays; for (int off = 32; off > 0; off >>= 1) r += (uint32_t)__shfl_xor((int)r, off, 64); dg.rays = r; }
+      dg.rays = n_rays;
       if (lane_id() == 0) {
         unsigned long long* o = st.stats + (size_t)kStatShards * kStatStride + 8;
         const unsigned long long* v = (const unsigned long long*)&dg;
@@ -1140,7 +1145,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
     if (tid < kNumShadeQueues) st.c_shade[tid * st.n_seg + seg0] = s_cnt[tid];      // the range's lists start in its first segment's storage
     __syncthreads();
   }
-  stat_accumulate(&s_stat[ST_SEGMENTS], n_rays);
+  stat_accumulate(&s_stat[ST_SEGMENTS], lane_id() == 0 ? n_rays : 0u);
   if (COUNT) { stat_accumulate(&s_stat[ST_NODE_VISITS], n_vis); stat_accumulate(&s_stat[ST_PRIM_TESTS], n_tst); }
   __syncthreads();
   stat_flush(st.stats, s_stat);
@@ -1435,7 +1440,7 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
 // (their k_shade wrote this iteration's shadow lists).  Same workgroup ranges and the same dynamic ray
 // fetch as k_trace; the work list is the concatenation of the range's per-BSDF shadow lists.
 template <bool COUNT, bool SORTED>
-__global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
+__global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc, DevState st, uint32_t mt_mask, const float4* __restrict__ flat_prims, uint32_t spb) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t s_pref[8];                                    // prefix over the range's per-BSDF shadow lists (k_shade writes one per range)
   __shared__ uint32_t s_next;
