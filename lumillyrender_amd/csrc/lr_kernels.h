@@ -106,7 +106,7 @@ template <bool SHADOW>
 struct Trav {
   V3 o, d;
   float ix, iy, iz;
-  float cull, dist, t;
+  float dist, t;
   int prim, cur, sp;
   bool occluded;
   uint32_t visits, tests;
@@ -119,7 +119,6 @@ template <bool SHADOW>
 LR_DEV void trav_begin(Trav<SHADOW>& s, V3 o, V3 d, float dist) {
   s.o = o; s.d = d; s.dist = dist;
   s.t = 3.0e38f; s.prim = -1; s.occluded = false; s.visits = 0; s.tests = 0;
-  s.cull = SHADOW ? dist + 2.0f * kEps : 3.0e38f;             // box-pruning bound
   s.cur = 0; s.sp = 0;
   {
 #pragma clang fp contract(fast)
@@ -193,6 +192,7 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - s.o.z) * s.iz;
     // t(q) is monotonic in q with the sign of 1/d: the ray enters a slab through the lower plane when it travels up the
     // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
+    const float bound = SHADOW ? s.dist + 2.0f * kEps : s.t;         // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
@@ -205,7 +205,7 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
       float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
       float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
       float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
-      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, SHADOW ? s.cull : s.t));            \
+      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, bound));                            \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
     LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)
@@ -1476,7 +1476,7 @@ __global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc,
         float4 ro = st.ray_o[slot], sd = st.sh_d[slot];             // shade advanced ray_o to the hit point = shadow origin (scene.rs:114-117)
         V3 o = v3(ro), dir = v3(sd);
         TraceResult r = traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w);
-        n_q += 1;
+        n_q += (uint32_t)__builtin_popcountll(__ballot(true));
         if (COUNT) n_tst += r.tests;
         shadow_resolve(sc, st, slot, o, dir, r);
       }
@@ -1533,8 +1533,9 @@ __global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc,
         if (drew) {
           float4 ro = st.ray_o[slot], sd = st.sh_d[slot];
           trav_begin<true>(tr, v3(ro), v3(sd), sd.w);
-          has = true; n_q += 1;
+          has = true;
         }
+        n_q += (uint32_t)__builtin_popcountll(__ballot(drew));       // counted per wave (a scalar)
         if (__ballot(has) == 0) break;                              // every drawn entry is a ray: empty wave = list exhausted
         const int thresh = exhausted ? 0 : kRefillBelow;
         bool go = has && !fin;
@@ -1543,7 +1544,7 @@ __global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc,
       }
     }
   }
-  stat_accumulate(&s_stat[ST_SHADOW], n_q);
+  stat_accumulate(&s_stat[ST_SHADOW], lane_id() == 0 ? n_q : 0u);
   if (COUNT) { stat_accumulate(&s_stat[ST_SHADOW_VISITS], n_vis); stat_accumulate(&s_stat[ST_SHADOW_TESTS], n_tst); }
   __syncthreads();
   stat_flush(st.stats, s_stat);
