@@ -321,6 +321,20 @@ def main():
                          "the roof this kernel is under is VALU issue, see roofline_valu") if resident else
                         "streaming pipeline: path state moves through HBM / Infinity Cache every iteration; traffic = PMC bytes of this kernel per launch",
             }
+            # ---- streaming pipeline: the bandwidth-bound stage beside the traversal (k_shade_all), MEASURED bytes over this run's launch time ----
+            if not resident and got and acc["kernel_timed"][abi.LR_K_SHADE]:
+                sh_bytes = got[1].get("k_shade_all_hbm_bytes_per_launch")
+                if sh_bytes:
+                    sh_ms = acc["kernel_ms"][abi.LR_K_SHADE] / acc["kernel_timed"][abi.LR_K_SHADE]
+                    alone = got[1].get("k_shade_all_hbm_GBps_in_pmc_pass")
+                    out["roofline_shade"] = {
+                        "kernel": "k_shade_all", "bound": "hbm", "achieved": round(sh_bytes / (sh_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(sh_bytes / (sh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": sh_bytes, "traffic_source": traffic_src,
+                        "avg_launch_ms": round(sh_ms, 5), "alone_GBps_in_pmc_pass": alone,
+                        "alone_frac": round(alone / HBM_PEAK_GBS, 5) if alone else None,
+                        "note": "PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the committed pass of this workload over this run's launch time; the launch "
+                                "shares the GPU with the other slot groups' traversal kernels -- alone (serialised profiler pass) it moves alone_GBps",
+                    }
             # ---- the VALU-issue roof (what bounds k_resident): instructions from a committed PMC profile of this workload ----
             gotp = load_profile("pmc", args.config, want)
             if gotp:
