@@ -1,7 +1,8 @@
 // lr_kernels.h -- the wavefront path-tracing kernels for gfx950 (wave64, 256-thread workgroups).
 //
-// One iteration of the render loop is   trace -> shade<bsdf> (one launch per BSDF present, plus
-// the miss/sky launch) -> shadow.   Paths never leave their slot: a path that ends regenerates
+// One iteration of the render loop is   trace -> shade -> shadow.   The shade stage is k_shade_all (one launch over the
+// slots themselves, every class of vertex under its lane mask) or, with LR_DENSE=0, one k_shade<bsdf> launch per BSDF
+// present plus the miss/sky launch over the lists k_trace then writes.  Paths never leave their slot: a path that ends regenerates
 // the next camera sample of its work item in place, so every slot is live until the work-item
 // dispenser runs dry ("persistent" path slots; workgroups are grid-strided over them).
 // Two pipelines run these stages over the same device functions: the STREAMING kernels below (state in
@@ -12,6 +13,7 @@
 //   k_trace      bvh.rs:130-141 + aabb.rs:74-92 + triangle.rs:69-100 + sphere.rs:42-63
 //                closest hit; LDS-staged per-lane traversal stack; epilogue compacts slot ids into
 //                one queue per BSDF with __ballot / popcount prefix sums
+//   k_shade_all  the same vertex code as k_shade<M> below for every slot of a range in slot order
 //   k_shade<M>   scene.rs:153-193 (emission, Russian roulette, direct-light sample, BSDF sample),
 //                material/*.rs for M, sky.rs for the miss queue, main.rs:92-121 for the per-sample
 //                accumulation; pushes NEE-eligible slots to the shadow queue
