@@ -397,13 +397,16 @@ def test_standalone_driver_writes_the_same_png(dev, tmp_path):
     scene.close()
 
 
-def test_two_rank_bench_assembles_the_single_rank_film(tmp_path):
+@pytest.mark.parametrize("config", ["c2", "c4"])
+def test_two_rank_bench_assembles_the_single_rank_film(tmp_path, config):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), both ranks on this
     box's one GPU: the film assembled in host shared memory equals the 1-rank film bit for bit, and the JSON line is the
-    stated workload (strong scaling by default)."""
+    stated workload (strong scaling by default).  c2 = the resident pipeline, c4 = the streaming one (mesh scene)."""
     import json
+    if config == "c4" and not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "1", "--warmup", "0", "--width", "192", "--height", "128", "--spp", "16", "--no-cpu-baseline", "--tile", "32"]
+    common = ["--config", config, "--steps", "1", "--warmup", "0", "--width", "192", "--height", "128", "--spp", "16", "--no-cpu-baseline", "--tile", "32"]
     one = tmp_path / "one.npy"
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-film", str(one)] + common,
                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
