@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LR_ABI_VERSION 1
+#define LR_ABI_VERSION 2
 
 /* error codes */
 #define LR_OK            0
@@ -154,6 +154,7 @@ typedef struct LrRenderParams {
 #define LR_FLAG_COUNT   2            /* count segments / shadow rays / node visits / prim tests */
 #define LR_FLAG_STREAMING 4          /* force the multi-kernel streaming pipeline (state in HBM)      */
 #define LR_FLAG_RESIDENT  8          /* force the single-launch resident pipeline (state in LDS) if it fits */
+#define LR_FLAG_FUSED     16         /* force the fused pipeline: one persistent launch, every lane carries its path in registers */
 
 typedef struct LrTile { int32_t x0, y0, w, h; } LrTile;
 
@@ -164,7 +165,8 @@ typedef struct LrTile { int32_t x0, y0, w, h; } LrTile;
 #define LR_K_SHADOW   3
 #define LR_K_RESOLVE  4
 #define LR_K_RESIDENT 5              /* the resident pipeline's single launch (trace/shade/shadow phases) */
-#define LR_K_COUNT    6
+#define LR_K_PATH     6              /* the fused pipeline's single launch (k_path_*: a lane carries its path)   */
+#define LR_K_COUNT    7
 
 typedef struct LrStats {
   uint64_t samples;                  /* camera samples completed                             */
@@ -183,7 +185,7 @@ typedef struct LrStats {
   double   upload_ms;                /* lr_scene_create                                      */
   double   bvh_build_ms;             /* device LBVH build inside lr_scene_create (0 = host tree) */
   uint64_t path_slots;               /* path-state slots the last render ran with                */
-  uint64_t pipeline;                 /* 1 = resident (one launch, state in LDS), 0 = streaming   */
+  uint64_t pipeline;                 /* 2 = fused (one launch, state in registers), 1 = resident (one launch, state in LDS), 0 = streaming */
 } LrStats;
 
 typedef struct LrScene LrScene;      /* opaque */

@@ -5,7 +5,7 @@ struct against the values the C side reports (lr_host_sizeof / lr_sizeof).
 """
 import ctypes as C
 
-LR_ABI_VERSION = 1
+LR_ABI_VERSION = 2
 
 LR_OK, LR_EINVAL, LR_EDEVICE, LR_ENOMEM, LR_EUNSUPPORTED, LR_EIO = 0, -1, -2, -3, -4, -5
 
@@ -14,9 +14,9 @@ LR_MAT_LAMBERT, LR_MAT_PHONG, LR_MAT_BLINN_PHONG, LR_MAT_GGX, LR_MAT_IDEAL_REFRA
 LR_PRIM_TRIANGLE, LR_PRIM_SPHERE = 0, 1
 LR_SKY_UNIFORM, LR_SKY_IBL = 0, 1
 LR_INTEGRATOR_PT, LR_INTEGRATOR_PT_DIRECT = 0, 1
-LR_FLAG_PROFILE, LR_FLAG_COUNT, LR_FLAG_STREAMING, LR_FLAG_RESIDENT = 1, 2, 4, 8
-LR_K_GENERATE, LR_K_TRACE, LR_K_SHADE, LR_K_SHADOW, LR_K_RESOLVE, LR_K_RESIDENT, LR_K_COUNT = 0, 1, 2, 3, 4, 5, 6
-LR_KERNEL_NAMES = ["generate", "trace", "shade", "shadow", "resolve", "resident"]
+LR_FLAG_PROFILE, LR_FLAG_COUNT, LR_FLAG_STREAMING, LR_FLAG_RESIDENT, LR_FLAG_FUSED = 1, 2, 4, 8, 16
+LR_K_GENERATE, LR_K_TRACE, LR_K_SHADE, LR_K_SHADOW, LR_K_RESOLVE, LR_K_RESIDENT, LR_K_PATH, LR_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+LR_KERNEL_NAMES = ["generate", "trace", "shade", "shadow", "resolve", "resident", "path"]
 
 f32 = C.c_float
 i32 = C.c_int32

@@ -747,10 +747,13 @@ LR_DEV int emitter_index(const DevScene& sc, float roulette) {
   }
   return k;
 }
-LR_DEV void sample_emission(const DevScene& sc, const Draw4& d, V3* value, float* pdf) {
+// `st` says where the emitter rows are read from: the scene blob (DevState) or a copy the kernel staged in LDS (lr_path.h)
+LR_DEV float4 emit_row(const DevState&, const DevScene& sc, int i) { return sc.emit[i]; }
+template <class ST>
+LR_DEV void sample_emission(const DevScene& sc, const ST& st, const Draw4& d, V3* value, float* pdf) {
   float roulette = sc.emission_area * d.v[1];
   int k = emitter_index(sc, roulette);
-  float4 e0 = sc.emit[3 * k], e1 = sc.emit[3 * k + 1], e2 = sc.emit[3 * k + 2];
+  float4 e0 = emit_row(st, sc, 3 * k), e1 = emit_row(st, sc, 3 * k + 1), e2 = emit_row(st, sc, 3 * k + 2);
   if (__float_as_uint(e0.w) == LR_PRIM_TRIANGLE) {
     float u = d.v[2], v = d.v[3];
     float mn = fmin_rs(u, v), mx = fmax_rs(u, v);
@@ -1165,8 +1168,9 @@ struct VertexOut { bool finished, has_shadow; V3 L; float g_term; uint32_t pixel
 struct VertexIn { float4 ro, rd, th, ra; float2 h; float4 sh, m0, m1, m2; };
 
 // MT = the BSDF type, kQMiss, or kMtDyn: type per lane (`mt`, one of MASK's bits), see material_*_dyn
-template <int MT, uint32_t MASK = 0>
-LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, const VertexIn& in, int mt = MT) {
+// ST = where the vertex's outputs go: DevState (rows of the slot in HBM or LDS) or the lane's own registers (lr_path.h)
+template <int MT, uint32_t MASK = 0, class ST>
+LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& rp, uint32_t slot, const VertexIn& in, int mt = MT) {
   VertexOut out; out.finished = false; out.has_shadow = false; out.sky_fetch = false;
   const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
   const float4 ro = in.ro, rd = in.rd, th = in.th, ra = in.ra;
@@ -1203,7 +1207,7 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, const DevState& st, const
       // ---- direct light (scene.rs:104-151); the occlusion test itself is the shadow stage ----
       if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
         V3 lp; float lpdf;
-        sample_emission(sc, d1, &lp, &lpdf);
+        sample_emission(sc, st, d1, &lp, &lpdf);
         V3 direct_path = lp - pos;
         float d2 = sqr_norm(direct_path);
         float dist = __builtin_sqrtf(d2);

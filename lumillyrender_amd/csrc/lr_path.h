@@ -1,0 +1,532 @@
+// lr_path.h -- the FUSED pipeline: one persistent launch in which every LANE carries its path from the camera sample to
+// its end (scene.rs:78-102,173-193 is one recursion per sample; here one loop per lane).
+//
+// The streaming and resident pipelines of lr_kernels.h move path state between stages -- through HBM, or through LDS with
+// three workgroup barriers per iteration.  Here the state (ray, throughput, radiance, pixel, sample, the pending
+// direct-light connection) never leaves the lane's registers, waves never wait for each other, and the stages are plain
+// code in the lane's loop:
+//
+//   finish     main.rs:92-121: fold the finished sample into the chunk sum, draw the next work item, next camera sample
+//   trace      closest hit of the lane's ray AND, in the same pass over the primitives, the visibility test of the
+//              direct-light connection the previous vertex left behind: both rays leave the same point (scene.rs:94-97,
+//              112-117), so per triangle  tv = o - p0,  qv = tv x e1  and  e2 . qv  (17 of the 57 operations of
+//              triangle.rs:69-100), per sphere  co  and  |co|^2,  and the scalar row loads are computed once for the pair.
+//              Every remaining operation keeps its operands and its order: the hits are the same bits.
+//   resolve    scene.rs:127-147 for the connection just tested
+//   shade      scene.rs:153-193 (shade_vertex_core, the same function the other pipelines call)
+//
+// Same device functions, same RNG keys, same chunk order and the same order of additions into a sample's radiance as the
+// other pipelines => bit-identical films (tests/test_gpu_parity_r3.py).
+//
+// Work items come from a per-WAVE pool held in scalar registers; its refill is a global atomic issued one iteration ahead,
+// so nobody waits for the dispenser.
+#pragma once
+#include "lr_kernels.h"
+
+namespace lr {
+
+typedef RowVec __attribute__((address_space(3))) LdsRow;
+
+// The lane's path state in the row format shade_vertex_core reads and writes (lr_device.h "Path state").
+struct LaneRow { float4 v; LR_DEV float4& operator[](uint32_t) { return v; } };
+template <bool LDS_TABLES>
+struct LaneStateT {
+  LaneRow ray_o, ray_d, thr, rad, sh_d, sh_w;
+  const LdsRow* emit;                  // LDS_TABLES: the emitter rows, staged by the kernel
+};
+template <bool LDS_TABLES>
+LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int i) {
+  if constexpr (LDS_TABLES) return row4(st.emit[i]);
+  else return sc.emit[i];
+}
+
+// ---- wave-level work-item pool: two ranges of reserved item ids in scalar registers + one refill in flight ----
+struct WavePool { uint32_t r0, a0, r1, a1; };
+
+// ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
+struct PairHit { float t; int prim; float st; int sprim; bool occluded; };
+
+LR_DEV bool sphere_test_co(V3 co, float co2, float r2, V3 d, float* t_out) {     // sphere.rs:42-55 given co = o - c and |co|^2
+  float cod = dot(co, d);
+  float det = cod * cod - co2 + r2;
+  if (det <= 0.0f) return false;
+  float sq = __builtin_sqrtf(det);
+  float t1 = -cod - sq;
+  float t2 = -cod + sq;
+  if (t1 < kEps && t2 < kEps) return false;
+  *t_out = t1 > kEps ? t1 : t2;
+  return true;
+}
+
+LR_DEV void flat_test_pair(float4 q0, float4 q1, float4 q2, V3 o, V3 d, V3 sd, float sdist, bool has_sh, PairHit& r) {
+  uint32_t idw = __float_as_uint(q0.w);
+  int id = (int)(idw & 0x7fffffffu);
+  float tA = 0.0f, tB = 0.0f; bool hitA = false, hitB = false;
+  if (idw >> 31) {
+    V3 co = o - v3(q0);
+    float co2 = sqr_norm(co);
+    hitA = sphere_test_co(co, co2, q1.y, d, &tA);
+    hitB = sphere_test_co(co, co2, q1.y, sd, &tB) & has_sh;
+  } else {
+    // triangle.rs:69-100 twice; tv, qv and e2 . qv depend on the origin only
+    V3 p0 = v3(q0), e1 = v3(q1), e2 = v3(q2);
+    V3 tv = o - p0;
+    V3 pvA = cross(d, e2);
+    float detA = dot(e1, pvA);
+    float invA = rcp_exact_mid(detA);
+    float uA = dot(tv, pvA) * invA;
+    bool okA = bool(!(__builtin_fabsf(detA) < kEps)) & bool(!(uA < 0.0f)) & bool(!(uA > 1.0f));
+    V3 pvB = cross(sd, e2);
+    float detB = dot(e1, pvB);
+    float invB = rcp_exact_mid(detB);
+    float uB = dot(tv, pvB) * invB;
+    bool okB = has_sh & bool(!(__builtin_fabsf(detB) < kEps)) & bool(!(uB < 0.0f)) & bool(!(uB > 1.0f));
+    if (__ballot(okA | okB) != 0) {
+      V3 qv = cross(tv, e1);
+      float vA = dot(d, qv) * invA;
+      okA = okA & bool(!(vA < 0.0f)) & bool(!(uA + vA > 1.0f));
+      float vB = dot(sd, qv) * invB;
+      okB = okB & bool(!(vB < 0.0f)) & bool(!(uB + vB > 1.0f));
+      if (__ballot(okA | okB) != 0) {
+        float eq = dot(e2, qv);
+        tA = eq * invA;
+        hitA = okA & bool(!(tA < kEps));
+        tB = eq * invB;
+        hitB = okB & bool(!(tB < kEps));
+      }
+    }
+  }
+  bool betterA = hitA & bool(tA < r.t);                  // rows come in primitive-id order: the first of equal hits is the lowest id
+  r.t = betterA ? tA : r.t;
+  r.prim = betterA ? id : r.prim;
+  float diff = tB - sdist;                               // scene.rs:127-131 window, as flat_test<true>
+  r.occluded = r.occluded | (hitB & bool(diff < -kEps));
+  hitB = hitB & bool(!(diff > kEps));
+  bool betterB = hitB & bool(tB < r.st);
+  r.st = betterB ? tB : r.st;
+  r.sprim = betterB ? id : r.sprim;
+}
+
+LR_DEV PairHit traverse_flat_pair(const float4* __restrict__ prims, int n, V3 o, V3 d, V3 sd, float sdist, bool has_sh) {
+  PairHit r; r.t = 3.0e38f; r.prim = -1; r.st = 3.0e38f; r.sprim = -1; r.occluded = false;
+  const ConstRow* rows = (const ConstRow*)prims;
+  for (int k = 0; k < n; k += 2) {
+    const ConstRow* nx = rows + 3 * k;
+    float4 a0 = row4(nx[0]), a1 = row4(nx[1]), a2 = row4(nx[2]);
+    float4 b0 = row4(nx[3]), b1 = row4(nx[4]), b2 = row4(nx[5]);    // unconditional: the array is padded
+    asm volatile("" :: "s"(a2.x), "s"(a2.y), "s"(a2.z));
+    flat_test_pair(a0, a1, a2, o, d, sd, sdist, has_sh, r);
+    if (k + 1 >= n) break;
+    flat_test_pair(b0, b1, b2, o, d, sd, sdist, has_sh, r);
+  }
+  return r;
+}
+
+// ---- stages shared by the flat and the tree kernel -------------------------------------------------------------------
+
+// scene.rs:127-147 for the connection the lane carries: (o, dir = sh_d.xyz) reached primitive `sprim` at distance `t`
+template <class RecFn>
+LR_DEV V3 path_shadow_resolve(V3 L, V3 o, V3 dir, V3 W, bool occluded, int sprim, float t, RecFn rec) {
+  if (!occluded && sprim >= 0) {
+    V3 pos = o + dir * t;
+    float4 sh = rec(sprim, 0), em = rec(sprim, 2);
+    uint32_t mw = __float_as_uint(sh.w);
+    V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
+    float light_cos = dot(-dir, light_normal);
+    if (light_cos > 0.0f) L = L + W * v3(em) * light_cos;
+  }
+  return L;
+}
+
+// Everything a lane keeps besides its LaneState rows; chunk sum, item and chunk end live in LDS (touched once per sample).
+struct PathCtl {
+  bool has_sh;                         // sh_d / sh_w hold a direct-light connection that is still to be tested
+  bool finished;                       // the sample in rad ended (its radiance is complete)
+  bool fresh;                          // no work item yet
+};
+
+#ifndef LR_PATH_WAVES
+#define LR_PATH_WAVES 6
+#endif
+constexpr int kRecStride = 5;          // float4 rows per staged shading record: 80 B, so 16 records start in 16 different bank groups
+
+// main.rs:92-121 for the lanes whose sample ended (or that have no item yet): fold into the chunk sum, draw the next work
+// item from the wave's pool, start the next camera sample.  Whole (converged) wave.  Returns false for a lane that retired.
+template <class LS>
+LR_DEV void path_finish(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, WavePool& pool,
+                        uint32_t& pend, bool& pending, bool& dry, LdsRow* s_acc, uint32_t* s_end, uint32_t& n_done) {
+  const uint32_t tid = threadIdx.x;
+  bool need_item = c.fresh;
+  uint32_t item = 0, end = 0;
+  uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w);
+  V3 sum = v3(0, 0, 0);
+  if (c.finished) {
+    float4 a = row4(s_acc[tid]);
+    item = __float_as_uint(a.w);
+    end = s_end[tid];
+    V3 delta = v3(ls.rad.v);
+    if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (delta * ls.ray_d.v.w) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
+    sum = v3(a) + delta;
+    sample += 1;
+    if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
+  }
+  n_done += (uint32_t)__builtin_popcountll(__ballot(c.finished));
+  const uint64_t nm = __ballot(need_item);
+  bool retired = false;
+  if (nm != 0) {
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(nm);
+    if (pending && cnt > pool.a0 + pool.a1) {                       // the refill issued an iteration ago
+      uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+      pending = false;
+      if (nb < st.n_items) { pool.r1 = nb; pool.a1 = st.n_items - nb < st.pool_batch ? st.n_items - nb : st.pool_batch; }
+      else dry = true;
+      if (pool.a0 == 0) { pool.r0 = pool.r1; pool.a0 = pool.a1; pool.a1 = 0; }
+    }
+    const uint32_t k = rank_in_mask(nm);
+    const bool short_of = need_item && !(k < pool.a0 + pool.a1);
+    uint32_t direct = 0xffffffffu;
+    if (!dry && !pending) direct = wave_reserve(st.next_item, short_of);   // pool empty and nothing in flight (start of the render, tiny jobs)
+    if (need_item) {
+      if (k < pool.a0) item = pool.r0 + k;
+      else if (k - pool.a0 < pool.a1) item = pool.r1 + (k - pool.a0);
+      else if (direct < st.n_items) item = direct;
+      else retired = true;
+      if (!retired) {
+        uint32_t chunk = item / st.n_pix, rank = item - chunk * st.n_pix;
+        pixel = st.rank_pixel[rank];
+        sample = chunk * st.chunk_spp;
+        end = sample + st.chunk_spp;
+        if (end > (uint32_t)rp.spp) end = (uint32_t)rp.spp;
+        sum = v3(0, 0, 0);
+      }
+    }
+    // advance the pool by what was handed out (wave-uniform)
+    uint32_t t0 = cnt < pool.a0 ? cnt : pool.a0;
+    pool.r0 += t0; pool.a0 -= t0;
+    uint32_t rest = cnt - t0, t1 = rest < pool.a1 ? rest : pool.a1;
+    pool.r1 += t1; pool.a1 -= t1;
+    if (pool.a0 == 0) { pool.r0 = pool.r1; pool.a0 = pool.a1; pool.a1 = 0; }
+    if (__ballot(short_of && !(direct < st.n_items)) != 0 && !pending) dry = true;
+  }
+  if (c.finished || c.fresh) {
+    if (retired) {
+      ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+    } else {
+      s_acc[tid] = (RowVec){sum.x, sum.y, sum.z, __uint_as_float(item)};
+      s_end[tid] = end;
+      Draw4 d0 = rng_block(rp.seed, pixel, sample, 0u);
+      uint32_t y = pixel / (uint32_t)sc.cam.res_w, x = pixel - y * (uint32_t)sc.cam.res_w;
+      V3 o, d; float g;
+      camera_sample(sc.cam, (int)x, (int)y, d0, &o, &d, &g);
+      ls.ray_o.v = make_float4(o.x, o.y, o.z, __int_as_float(0));
+      ls.ray_d.v = make_float4(d.x, d.y, d.z, g);
+      ls.thr.v = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
+      ls.rad.v = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
+    }
+  }
+  c.finished = false; c.fresh = false;
+}
+
+// One vertex for the lanes whose ray is done: hit -> scene.rs:153-193, miss -> sky.  `rec(prim, row)` reads the 64-B shading
+// record.  Leaves the next ray (and possibly a connection to test) in ls, or c.finished with the final radiance in ls.rad.
+template <uint32_t MTS, class LS, class RecFn>
+LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl& c, bool live, float t, int prim, RecFn rec, uint32_t& n_sky) {
+  const bool hitv = live && prim >= 0, miss = live && prim < 0;
+  if (hitv) {
+    VertexIn in;
+    in.ro = ls.ray_o.v; in.rd = ls.ray_d.v; in.th = ls.thr.v; in.ra = ls.rad.v;
+    in.h = make_float2(t, __int_as_float(prim));
+    in.sh = rec(prim, 0); in.m0 = rec(prim, 1); in.m1 = rec(prim, 2); in.m2 = rec(prim, 3);
+    VertexOut v;
+    if constexpr ((MTS & (MTS - 1u)) == 0u) {
+      constexpr int K = MTS == 1u ? 0 : (MTS == 2u ? 1 : (MTS == 4u ? 2 : (MTS == 8u ? 3 : 4)));
+      v = shade_vertex_core<K>(sc, ls, rp, 0u, in);
+    } else {
+      v = shade_vertex_core<kMtDyn, MTS>(sc, ls, rp, 0u, in, (int)__float_as_uint(in.m0.w));
+    }
+    c.has_sh = v.has_shadow;
+    if (v.finished) { c.finished = true; ls.rad.v = make_float4(v.L.x, v.L.y, v.L.z, in.ra.w); }
+  }
+  if (__ballot(miss) != 0) {
+    if (miss) {                                                      // scene.rs:29 / :43
+      V3 L = v3(ls.rad.v) + v3(ls.thr.v) * sky_radiance(sc, v3(ls.ray_d.v));
+      ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+      c.finished = true;
+    }
+    if (sc.sky_type == LR_SKY_IBL) n_sky += (uint32_t)__builtin_popcountll(__ballot(miss));
+  }
+}
+
+// =====================================================================================================================
+// Flat scenes (<= kFlatMax primitives): every lane tests every primitive, rows through the scalar cache (traverse_flat).
+// Nothing in the loop diverges except the stages' own lane masks.
+// =====================================================================================================================
+template <uint32_t MTS>
+__global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc, DevState st, DevParams rp, const float4* __restrict__ flat_prims) {
+  __shared__ RowVec s_rec[kFlatMax * kRecStride];
+  __shared__ RowVec s_emit[kFlatMax * 3];
+  __shared__ RowVec s_acc[kBlock];
+  __shared__ uint32_t s_end[kBlock];
+  __shared__ uint32_t s_stat[ST_COUNT];
+  const uint32_t tid = threadIdx.x;
+  if (tid < ST_COUNT) s_stat[tid] = 0;
+  for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 4u; i += kBlock) {
+    float4 v = sc.shade[i];
+    s_rec[(i >> 2) * kRecStride + (i & 3u)] = (RowVec){v.x, v.y, v.z, v.w};
+  }
+  for (uint32_t i = tid; i < (uint32_t)sc.n_emitters * 3u && i < (uint32_t)kFlatMax * 3u; i += kBlock) {
+    float4 v = sc.emit[i];
+    s_emit[i] = (RowVec){v.x, v.y, v.z, v.w};
+  }
+  __syncthreads();
+  auto rec = [&](int prim, int row) -> float4 { return row4(((const LdsRow*)s_rec)[prim * kRecStride + row]); };
+
+  LaneStateT<true> ls;
+  ls.emit = (const LdsRow*)s_emit;
+  ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+  ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
+  WavePool pool = {0, 0, 0, 0};
+  uint32_t pend = 0; bool pending = false, dry = false;
+  uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;                // wave-uniform: only touched where the wave is converged
+  while (true) {
+    // ---- refill the wave's pool one iteration ahead of need ----
+    if (!pending && !dry && pool.a1 == 0 && pool.a0 < st.pool_low) {
+      pend = 0;
+      if (lane_id() == 0) pend = atomicAdd(st.next_item, st.pool_batch);
+      pending = true;
+    }
+    // ---- finish: fold, next item, next camera sample ----
+    if (__ballot(c.finished || c.fresh) != 0)
+      path_finish(sc, st, rp, ls, c, pool, pend, pending, dry, (LdsRow*)s_acc, s_end, n_done);
+    const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
+    const uint64_t lm = __ballot(live);
+    if (lm == 0) break;
+    n_seg += (uint32_t)__builtin_popcountll(lm);
+    const uint64_t sm = __ballot(live && c.has_sh);
+    n_shq += (uint32_t)__builtin_popcountll(sm);
+    // ---- trace: closest hit + the pending connection, one pass over the primitive rows ----
+    float t = 3.0e38f; int prim = -1;
+    if (live) {
+      const V3 o = v3(ls.ray_o.v), d = v3(ls.ray_d.v);
+      if (sm != 0) {
+        const V3 sd = c.has_sh ? v3(ls.sh_d.v) : d;
+        PairHit h = traverse_flat_pair(flat_prims, sc.n_flat, o, d, sd, ls.sh_d.v.w, c.has_sh);
+        t = h.t; prim = h.prim;
+        if (c.has_sh) {
+          V3 L = path_shadow_resolve(v3(ls.rad.v), o, sd, v3(ls.sh_w.v), h.occluded, h.sprim, h.st, rec);
+          ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+          c.has_sh = false;
+        }
+      } else {
+        TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f);
+        t = r.t; prim = r.prim;
+      }
+    }
+    // ---- vertex: shade the hit or fold the sky ----
+    path_vertex<MTS>(sc, rp, ls, c, live, t, prim, rec, n_sky);
+  }
+  if (lane_id() == 0) {
+    atomicAdd(&s_stat[ST_SEGMENTS], n_seg); atomicAdd(&s_stat[ST_SHADOW], n_shq);
+    atomicAdd(&s_stat[ST_SAMPLES], n_done); atomicAdd(&s_stat[ST_SKY], n_sky);
+  }
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
+}
+
+
+// =====================================================================================================================
+// Tree scenes: the persistent while-while traversal of k_trace, with SHADING AS THE REFILL.  A lane walks the rays of its
+// own path -- first the direct-light connection its last vertex left (a visibility query, scene.rs:127-131), then the
+// continuation ray -- and whenever at most half of the wave is still walking, the wave stops at a converged RETIRE POINT:
+// finished connections are resolved and their lanes start the continuation ray; finished continuation rays are shaded
+// right there (scene.rs:153-193) or fold the sky, paths that ended fold into their chunk sum and start the next camera
+// sample; every such lane leaves the retire point with a new ray.  No ray, hit, throughput or radiance row ever goes to
+// HBM, and an iteration is not three launches but a branch.
+// The traversal differs from trav_node / trav_leaf (lr_kernels.h) in two ways only: the query kind is a per-lane flag
+// (lanes of one wave walk connections and continuation rays side by side), and the origin is the path's (ls.ray_o).
+// =====================================================================================================================
+struct PTrav {
+  V3 d; float ix, iy, iz;
+  float dist, t; int prim, cur, sp;
+  bool shadow, occluded;
+};
+
+LR_DEV void ptrav_begin(PTrav& s, V3 d, float dist, bool shadow) {
+  s.d = d; s.dist = dist; s.shadow = shadow;
+  s.t = 3.0e38f; s.prim = -1; s.occluded = false; s.cur = 0; s.sp = 0;
+  {
+#pragma clang fp contract(fast)
+    float dx = __builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x;     // see trav_begin
+    float dy = __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y;
+    float dz = __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z;
+    s.ix = __builtin_amdgcn_rcpf(dx); s.iy = __builtin_amdgcn_rcpf(dy); s.iz = __builtin_amdgcn_rcpf(dz);
+  }
+}
+LR_DEV bool ptrav_pop(const DevScene& sc, PTrav& s, const uint32_t* stk_n) {
+  if (s.sp > 0) { --s.sp; s.cur = (int)stack_load(sc, stk_n, s.sp); return true; }
+  return false;
+}
+// one 4-wide node (trav_node): boxes only prune, so fused / approximate arithmetic is allowed here
+LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
+  const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
+  float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
+  float k0, k1, k2, k3;
+  int r0 = __float_as_int(rc.x), r1 = __float_as_int(rc.y), r2 = __float_as_int(rc.z), r3 = __float_as_int(rc.w);
+  {
+#pragma clang fp contract(fast)
+    const float inf = __builtin_inff();
+    const uint32_t eb = __float_as_uint(g.w);
+    const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - o.x) * s.ix;
+    const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - o.y) * s.iy;
+    const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - o.z) * s.iz;
+    const float bound = s.shadow ? s.dist + 2.0f * kEps : s.t;       // the light's distance (+ the visibility window), or the closest hit so far
+    const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
+    const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
+    const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
+    const uint32_t nx = upx ? wlx : whx, fx = upx ? whx : wlx;
+    const uint32_t ny = upy ? wly : why, fy = upy ? why : wly;
+    const uint32_t nz = upz ? wlz : whz, fz = upz ? whz : wlz;
+#define LR_SLAB(K, C, R)                                                                                         \
+    {                                                                                                            \
+      float a0 = __builtin_fmaf(qbyte(nx, C), ax, bx), a1 = __builtin_fmaf(qbyte(fx, C), ax, bx);                \
+      float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
+      float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
+      float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
+      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, bound));                            \
+      K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
+    }
+    LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)
+#undef LR_SLAB
+    int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
+    if (n_hit == 0) return ptrav_pop(sc, s, stk_n);
+    order2(k0, r0, k1, r1); order2(k2, r2, k3, r3); order2(k0, r0, k2, r2); order2(k1, r1, k3, r3); order2(k1, r1, k2, r2);
+    if (n_hit == 4) { stack_store(sc, stk_n, s.sp, (uint32_t)r3); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 2, (uint32_t)r1); }
+    else if (n_hit == 3) { stack_store(sc, stk_n, s.sp, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r1); }
+    else if (n_hit == 2) { stack_store(sc, stk_n, s.sp, (uint32_t)r1); }
+    s.sp += n_hit - 1;
+    s.cur = r0;
+  }
+  return true;
+}
+// one leaf (trav_leaf): the primitive tests decide, exact arithmetic
+LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n) {
+  uint32_t enc = (uint32_t)~s.cur;
+  uint32_t first = enc >> 3, count = enc & 7u;
+  const float4* q = sc.prims + 3 * (size_t)first;
+  float4 n0 = q[0], n1 = q[1], n2 = q[2];
+  for (uint32_t k = 0; k < count; ++k) {
+    float4 q0 = n0, q1 = n1, q2 = n2;
+    if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
+    uint32_t idw = __float_as_uint(q0.w);
+    int id = (int)(idw & 0x7fffffffu);
+    float t; bool hit;
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, s.d, &t);
+    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, s.d, &t);
+    if (!hit) continue;
+    if (s.shadow) {
+      float diff = t - s.dist;
+      if (diff < -kEps) { s.occluded = true; return false; }
+      if (diff > kEps) continue;
+    }
+    if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }
+  }
+  return ptrav_pop(sc, s, stk_n);
+}
+LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go) {
+#pragma unroll 1
+  for (int it = 0; it < kDescendBurst; ++it) {
+    bool nm = go && s.cur >= 0;
+    if (__ballot(nm) == 0) break;
+    if (nm) go = ptrav_node(sc, s, o, stk_n);
+  }
+  if (go && s.cur < 0) go = ptrav_leaf(sc, s, o, stk_n);
+}
+
+#ifndef LR_PATHT_WAVES
+#define LR_PATHT_WAVES 4
+#endif
+
+template <uint32_t MTS>
+__global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene sc, DevState st, DevParams rp) {
+  extern __shared__ uint32_t lds[];                                  // traversal stack: sc.stack_lds entries per lane
+  __shared__ RowVec s_acc[kBlock];
+  __shared__ uint32_t s_end[kBlock];
+  __shared__ uint32_t s_stat[ST_COUNT];
+  uint32_t* stk_n = lds;
+  const uint32_t tid = threadIdx.x;
+  if (tid < ST_COUNT) s_stat[tid] = 0;
+  __syncthreads();
+  auto rec = [&](int prim, int row) -> float4 { return sc.shade[4 * (size_t)prim + row]; };
+
+  LaneStateT<false> ls;
+  ls.emit = nullptr;
+  ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+  ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
+  PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f), 0.0f, false);
+  bool has = false, fin = false;                                     // the lane has a ray in flight / its walk is over
+  WavePool pool = {0, 0, 0, 0};
+  uint32_t pend = 0; bool pending = false, dry = false;
+  uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;                // wave-uniform: only touched where the wave is converged
+  while (true) {
+    if (!pending && !dry && pool.a1 == 0 && pool.a0 < st.pool_low) {
+      pend = 0;
+      if (lane_id() == 0) pend = atomicAdd(st.next_item, st.pool_batch);
+      pending = true;
+    }
+    // ================= retire point (converged) =================
+    // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
+    {
+      const bool fs = has && fin && tr.shadow;
+      if (__ballot(fs) != 0) {
+        if (fs) {
+          V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), tr.d, v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
+          ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+          c.has_sh = false;
+          ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
+          fin = false;
+        }
+      }
+    }
+    // (b) continuation rays whose walk is over: the vertex
+    {
+      const bool fm = has && fin;                                      // (a) left only closest-hit walks with fin set
+      if (__ballot(fm) != 0) {
+        path_vertex<MTS>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, n_sky);
+        if (fm) { has = false; fin = false; }
+      }
+    }
+    // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
+    if (__ballot(c.finished || c.fresh) != 0)
+      path_finish(sc, st, rp, ls, c, pool, pend, pending, dry, (LdsRow*)s_acc, s_end, n_done);
+    // (d) every live lane without a ray starts its next one: the connection first, if its vertex left one
+    {
+      const bool start = !has && __float_as_int(ls.ray_o.v.w) >= 0;
+      n_seg += (uint32_t)__builtin_popcountll(__ballot(start));
+      n_shq += (uint32_t)__builtin_popcountll(__ballot(start && c.has_sh));
+      if (start) {
+        if (c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v), ls.sh_d.v.w, true);
+        else ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
+        has = true; fin = false;
+      }
+    }
+    const uint64_t hm = __ballot(has);
+    if (hm == 0) break;
+    // ================= walk until at most half of the wave's rays are still under way =================
+    const int live_n = __builtin_popcountll(hm);
+    const int thresh = live_n / 2 < kRefillBelow ? live_n / 2 : kRefillBelow;
+    const V3 o = v3(ls.ray_o.v);
+    bool go = has && !fin;
+    do { ptrav_burst(sc, tr, o, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+    fin = has && !go;
+  }
+  if (lane_id() == 0) {
+    atomicAdd(&s_stat[ST_SEGMENTS], n_seg); atomicAdd(&s_stat[ST_SHADOW], n_shq);
+    atomicAdd(&s_stat[ST_SAMPLES], n_done); atomicAdd(&s_stat[ST_SKY], n_sky);
+  }
+  __syncthreads();
+  stat_flush(st.stats, s_stat);
+}
+
+}  // namespace lr

@@ -17,6 +17,7 @@
 #include "../../include/lumilly_hip.h"
 #include "../../include/lumilly_hip_diag.h"
 #include "lr_kernels.h"
+#include "lr_path.h"
 #include "lr_lbvh.h"
 
 using namespace lr;
@@ -440,7 +441,7 @@ int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
 
 struct Launcher {
   LrScene& s; bool profile; int iter = 0;
-  bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || k == LR_K_RESIDENT || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
+  bool timed(int k) const { return profile && (k == LR_K_GENERATE || k == LR_K_RESOLVE || k == LR_K_RESIDENT || k == LR_K_PATH || iter % kProfileStride == 0) && s.pools[k].used < kEventPool; }
   template <class F> void run(int k, F&& launch, hipStream_t on = nullptr) {
     bool t = timed(k);
     EventPool& p = s.pools[k];
@@ -522,6 +523,19 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   bool resident = resident_lds <= (big_block ? 54 : 40) * 1024 && !count;
   if (rp_in.flags & LR_FLAG_STREAMING) resident = false;
   if ((rp_in.flags & LR_FLAG_RESIDENT) && resident_lds <= 156 * 1024 && !count) resident = true;
+  // fused: one persistent launch in which a lane carries its path in registers (lr_path.h); flat scenes
+  bool fused = false;
+  {
+    // default for flat scenes with ONE BSDF (the headline class: +10 % over the resident pipeline); with several
+    // BSDFs in a wave the per-lane material dispatch loses to the resident pipeline's per-BSDF lists (brdf row: 7.8 vs 9.6 G/s)
+    const char* pe = std::getenv("LR_PIPELINE");
+    const bool forced = (rp_in.flags & LR_FLAG_FUSED) || (pe && std::strcmp(pe, "fused") == 0);
+    if (s.dev.n_flat > 0 && !count && (forced || __builtin_popcount(present_mask) == 1)) fused = true;
+    if (s.dev.n_flat == 0 && !count && forced) fused = true;             // tree scenes: k_path_tree
+    if (pe && (std::strcmp(pe, "resident") == 0 || std::strcmp(pe, "streaming") == 0)) fused = false;
+    if (rp_in.flags & (LR_FLAG_STREAMING | LR_FLAG_RESIDENT)) fused = false;
+    if (fused) resident = false;
+  }
   const int resident_per_cu = big_block ? 3 : std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
   // streaming: enough slots that a k_trace workgroup pass covers many rays per lane (the run-down of a pass's last
   // rays is what idles lanes: 1 M slots = 4 rays per lane left 23 % of the lanes busy in a node step), but no more
@@ -529,6 +543,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(32u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * RB) : stream_slots);
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * RB));   // every workgroup must be resident: no grid-stride
+  if (fused) n_slots = (uint32_t)(s.n_cus * (s.dev.n_flat > 0 ? LR_PATH_WAVES : LR_PATHT_WAVES) * kBlock);   // one path per lane of every resident wave
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -588,7 +603,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   LrStats& S = s.stats;
   double keep_upload = S.upload_ms, keep_bvh = S.bvh_build_ms;
   std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload; S.bvh_build_ms = keep_bvh;
-  S.path_slots = n_slots; S.pipeline = resident ? 1 : 0;
+  S.path_slots = n_slots; S.pipeline = fused ? 2 : (resident ? 1 : 0);
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 32) * sizeof(unsigned long long), st));
@@ -609,7 +624,36 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
   Launcher L{s, profile};
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
-  if (n_items > 0 && resident) {
+  if (n_items > 0 && fused) {
+    uint32_t mt_mask = 0;
+    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+    const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
+    // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
+    ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
+    ds.pool_low = std::max<uint32_t>(1, ds.pool_batch / 2);
+    if (s.dev.n_flat == 0 && dsc.spill_depth > 0) {
+      s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
+      dsc.stack_spill = s.stack_spill.p;
+    }
+    const uint32_t only = mt_mask | 1u;                                // the kernels are instantiated for the BASELINE material sets and for "anything"
+    L.run(LR_K_PATH, [&] {
+      if (s.dev.n_flat > 0) {
+        if (mt_mask == 1u) hipLaunchKernelGGL(k_path_flat<1u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
+        else hipLaunchKernelGGL(k_path_flat<31u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
+      } else {
+        if (lds > 48 * 1024) {
+          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<9u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<31u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (only == 1u) hipLaunchKernelGGL(k_path_tree<1u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
+        else if (only == 9u) hipLaunchKernelGGL(k_path_tree<9u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
+        else hipLaunchKernelGGL(k_path_tree<31u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
+      }
+    });
+    S.iterations = 1;
+    HIP_OK(hipStreamSynchronize(st));
+  } else if (n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     if (RB == 512) { ds.pool_batch *= 2; ds.pool_low *= 2; }
@@ -809,7 +853,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
 extern "C" {
 
 const char* lr_last_error(void) { return g_err.c_str(); }
-const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=1"; }
+const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2"; }
 
 int lr_device_count(void) {
   int n = 0;

@@ -13,7 +13,9 @@ from . import abi
 from .host import LumillyError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblumilly_hip.so")
+# LR_HIP_LIB=<path> loads another build of the SAME library (diagnostic variants under build/: `make -C csrc diag stamp`);
+# there is still no fallback -- a missing file raises.
+_LIB_PATH = os.environ.get("LR_HIP_LIB") or os.path.join(_HERE, "liblumilly_hip.so")
 _lib = None
 
 

@@ -1,0 +1,99 @@
+"""GPU parity, round 3: the fused pipeline (csrc/lr_path.h: one persistent launch, a lane carries its path) against the
+other two pipelines and the oracle; full-size count / tiling properties of BASELINE configs 3-5; the RCCL branch of
+bench.py."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, scene_path
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lumillyrender_amd import device
+    assert device.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return device
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import binding
+    return binding
+
+
+def load(name, w, h, text_edit=None):
+    from lumillyrender_amd import host
+    if text_edit is None:
+        d = host.Description(scene_path(name))
+    else:
+        d = host.Description(text=text_edit(open(scene_path(name)).read()))
+    d.set_resolution(w, h)
+    return d
+
+
+def _generated_assets():
+    return os.path.exists(os.path.join(ROOT, "assets", "models", "blob", "blob.obj"))
+
+
+def _counters(st):
+    return (st.samples, st.segments, st.shadow_rays, st.sky_fetches)
+
+
+FLAT_CASES = [("cbox-spheres.toml", 1), ("cbox-spheres.toml", 0), ("brdf-row.toml", 1), ("brdf-row.toml", 0), ("two-spheres.toml", None)]
+
+
+@pytest.mark.parametrize("name,integ", FLAT_CASES)
+def test_fused_pipeline_is_bit_identical_on_flat_scenes(dev, oracle, name, integ):
+    """k_path_flat pairs the visibility test of a vertex's direct-light connection with the closest-hit test of the
+    continuation ray (one pass over the primitive rows, origin-only terms shared) and keeps the path in registers.  Every
+    operation that decides or rounds anything keeps its operands and order, so film and counters equal the resident
+    and the streaming pipeline's bit for bit, and all of them sit within tolerance of the oracle."""
+    from lumillyrender_amd import abi
+    desc = load(name, 72, 40)
+    scene = dev.Scene(desc)
+    films, stats = {}, {}
+    for label, flags in (("fused", abi.LR_FLAG_FUSED), ("resident", abi.LR_FLAG_RESIDENT), ("streaming", abi.LR_FLAG_STREAMING)):
+        films[label] = scene.render(desc.render_params(spp=24, seed=13, integrator=integ, flags=flags))
+        st = scene.stats()
+        stats[label] = _counters(st)
+        assert st.pipeline == {"fused": 2, "resident": 1, "streaming": 0}[label], (label, st.pipeline)
+    assert stats["fused"] == stats["resident"] == stats["streaming"]
+    assert stats["fused"][0] == 72 * 40 * 24
+    assert np.array_equal(films["fused"], films["resident"]) and np.array_equal(films["fused"], films["streaming"])
+    ref = oracle.render(desc, desc.render_params(spp=24, seed=13, integrator=integ))
+    assert float(np.nanmax(np.abs(films["fused"] - ref))) < TOL
+    scene.close()
+
+
+def test_fused_pipeline_edge_sizes(dev):
+    """Fewer work items than lanes, one pixel, a ragged tile list, spp that does not divide into chunks, and a frame with
+    more work items than one wave's pool batch: every sample is rendered exactly once (device counter) and the film equals
+    the resident pipeline's."""
+    from lumillyrender_amd import abi, host
+    for (w, h, spp) in ((1, 1, 1), (3, 2, 7), (16, 16, 3), (64, 48, 100), (200, 120, 37)):
+        desc = load("cbox-spheres.toml", w, h)
+        scene = dev.Scene(desc)
+        a = scene.render(desc.render_params(spp=spp, seed=3, flags=abi.LR_FLAG_FUSED))
+        st = scene.stats()
+        assert st.pipeline == 2 and st.samples == w * h * spp, (w, h, spp, st.samples)
+        b = scene.render(desc.render_params(spp=spp, seed=3, flags=abi.LR_FLAG_RESIDENT))
+        assert np.array_equal(a, b), (w, h, spp)
+        scene.close()
+    desc = load("cbox-spheres.toml", 96, 64)
+    scene = dev.Scene(desc)
+    p = desc.render_params(spp=20, seed=8, flags=abi.LR_FLAG_FUSED)
+    whole = scene.render(p)
+    out = np.zeros_like(whole)
+    for rank in range(3):
+        tiles, n = host.tiles(96, 64, 32, rank, 3)
+        scene.render(p, tiles, n, out=out)
+    assert np.array_equal(whole, out)
+    scene.close()
