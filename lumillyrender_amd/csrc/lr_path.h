@@ -444,7 +444,7 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, boo
 }
 
 #ifndef LR_PATHT_WAVES
-#define LR_PATHT_WAVES 4
+#define LR_PATHT_WAVES 6
 #endif
 
 template <uint32_t MTS>

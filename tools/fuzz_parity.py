@@ -102,7 +102,7 @@ def run(seed, W, H, spp, max_objs=26, hostile=False):
     want = oracle.render(desc, params, threads=0)
     scene = device.Scene(desc)
     worst = 0.0
-    for flags in (0, 4, 8):                                # default pipeline, forced streaming, forced resident (falls back to the default choice when it does not fit)
+    for flags in (0, 4, 8, 16):                            # default pipeline, forced streaming, forced resident (falls back to the default choice when it does not fit), forced fused
         params.flags = flags
         got = scene.render(params)
         assert scene.stats().samples == W * H * spp
