@@ -3,7 +3,7 @@
 
 Default workload = BASELINE.json configs[1] ("c2"): the reference's new-cbox scene (scenes/cbox-spheres.toml here),
 1024x1024, 1024 spp, pt-direct (next-event estimation), Lambert only.  One "step" = one full render of the frame
-through the C ABI (lr_render: wavefront kernels + read-back of the rendered tiles).  The scene (BVH, primitives,
+through the C ABI (lr_render: the path kernels + read-back of the rendered tiles).  The scene (BVH, primitives,
 materials, emitters, sky) is resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps K --warmup W [--config c2|c3|c4|c5]
@@ -12,6 +12,8 @@ materials, emitters, sky) is resident in HBM before the timed region starts.
 --config selects the other BASELINE.json configs at their full sizes (single-GPU lines of the 8-GPU configs):
   c3 brdf-row.toml 960x540 4096 spp (GGX row)      c4 mesh-box.toml 1920x1370 2048 spp pt (100k-triangle mesh)
   c5 ibl-lens.toml 2048x2048 8192 spp (thin lens, IBL sky, GGX mesh)
+A default run (c2, one GPU) also renders short legs of c3, c4 and c5 AFTER the headline's timed region and attaches them as
+`other_configs` (c5 at 1024 of its 8192 spp, labelled), so that one driver-run line carries a number for every config.
 
 Multi-GPU: one process per GPU, pixel tiles of the frame sharded round-robin over ranks, scene replicated, no
 collective on the data path; every rank's lr_render writes its tiles into one film in host shared memory.
@@ -19,13 +21,17 @@ collective on the data path; every rank's lr_render writes its tiles into one fi
 line; --scaling weak renders spp*N per pixel (per-GPU work fixed).
 
 The JSON line also carries
-  roofline       SURVEY 8(d) block for the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP
-                 events around the launches inside the timed region) against the 8 TB/s HBM peak, with the MEASURED
-                 HBM bytes (`traffic`, from profiles/<round>_traffic_<config>.json, attached only when the workload
-                 recorded there is this run's)
-  roofline_valu  the roof the resident kernel is really under: VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU,
-                 profiles/<round>_pmc_<config>.json) / launch duration against 1024 SIMDs x clock / 2 cycles per wave64
-                 instruction (MI355X_MICROARCH.md: v_fma_f32 2 cycles), transcendentals weighted twice
+  roofline       the roof the dominant kernel is under.  The path kernels (k_path_flat / k_path_tree / k_resident) keep
+                 the path state in registers or LDS and the scene in caches: they are bound by VALU ISSUE, not by HBM, so
+                 `bound` = "valu-issue": VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, transcendentals once
+                 more: they hold the port twice as long; from the committed profiles/<round>_pmc_<config>.json of THIS
+                 workload) / this run's mean launch duration (HIP events on the launch stream) against 1024 SIMDs x clock / 2
+                 cycles per wave64 instruction (MI355X_MICROARCH.md).  `traffic` = measured HBM bytes per launch (FETCH_SIZE x 2 +
+                 WRITE_SIZE passes, profiles/<round>_traffic_<config>.json).  A streaming-pipeline kernel (only with
+                 --streaming) reports its MEASURED bytes over its launch time against the 8 TB/s HBM peak.
+  roofline_hbm_nominal   SURVEY 8(d)'s algorithmic bytes per launch over the launch time -- what a wavefront design would stream;
+                 these kernels do not move them (see `traffic`), it is carried for comparison only and flagged `cache_served`
+                 when it exceeds what HBM could deliver
   cpu_baseline   the CPU oracle (a port of the reference algorithm, oracle/, built -O3 -mavx2) on this box's host cores,
                  on a bounded sample of the same frame
 """
@@ -44,6 +50,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 VALU_CYCLES_PER_WAVE_INSTR = 2.0   # MI355X_MICROARCH.md cycle constants: v_fma_f32 (wave64) 2 cycles on a SIMD-32
+NOMINAL_CLOCK_GHZ = 2.4        # used only when the PMC pass recorded no GRBM_GUI_ACTIVE
+
+# device record sizes the SURVEY 8(d) byte model prices (csrc/lr_device.h)
+NODE_BYTES_PER_CHILD_BOX = 16.0    # 64-B 4-wide node / 4 child boxes
+PRIM_BYTES = 48.0
 
 CONFIGS = {
     # name: scene, W, H, spp, integrator (None = the scene file's), description for config.workload, metric text
@@ -56,6 +67,8 @@ CONFIGS = {
     "c5": ("ibl-lens.toml", 2048, 2048, 8192, None, "the reference's scenes/welcome-2018.toml class: thin lens, HDR IBL sky, GGX mesh; pt-direct",
            "Msamples/sec (whole node), welcome-2018-class 2048x2048 8192 spp IBL"),
 }
+# legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp)
+OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 1024))
 
 
 def parse():
@@ -72,9 +85,11 @@ def parse():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 / c5 legs a default run attaches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--streaming", action="store_true", help="force the multi-kernel streaming pipeline")
+    ap.add_argument("--resident", action="store_true", help="force the resident pipeline (path state in LDS)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier (nccl = RCCL; testing: gloo)")
     ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: every rank renders on GPU 0")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the last film as .npy (tests)")
@@ -120,11 +135,11 @@ def cpu_baseline(desc, W, H, integ, cpu_seconds):
 
 
 def load_profile(kind, cfg, want):
-    """Newest (by the `when` stamp the export recorded, then by name) profiles/r*_{kind}_{cfg}.json whose recorded workload
-    equals `want` on every key of `want` (scene, film size, spp, slot count); None when there is none -- a figure from
+    """Newest (by the `when` stamp the export recorded, then by name) profiles/r*_{kind}_{cfg}*.json whose recorded workload
+    equals `want` on every key of `want` (scene, film size, spp, pipeline); None when there is none -- a figure from
     another workload is never attached."""
     best, best_key = None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_{cfg}.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}_{cfg}*.json"))):
         try:
             d = json.load(open(path))
         except Exception:
@@ -135,6 +150,178 @@ def load_profile(kind, cfg, want):
             if best_key is None or key > best_key:
                 best, best_key = (path, d), key
     return best
+
+
+def new_acc(abi):
+    return {"segments": 0, "shadow": 0, "samples": 0, "iterations": 0, "render_ms": 0.0, "path_slots": 0, "pipeline": 0,
+            "kernel_ms": [0.0] * abi.LR_K_COUNT, "kernel_timed": [0] * abi.LR_K_COUNT, "kernel_launches": [0] * abi.LR_K_COUNT}
+
+
+def add_stats(acc, st, abi):
+    acc["segments"] += st.segments; acc["shadow"] += st.shadow_rays; acc["samples"] += st.samples
+    acc["iterations"] += st.iterations; acc["render_ms"] += st.render_ms
+    acc["path_slots"] = int(st.path_slots); acc["pipeline"] = int(st.pipeline)
+    for k in range(abi.LR_K_COUNT):
+        acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]; acc["kernel_launches"][k] += st.kernel_launches[k]
+
+
+PIPELINE_NAMES = {0: "streaming", 1: "resident", 2: "fused"}
+
+
+def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, slots, flags):
+    """`roofline` (+ `roofline_hbm_nominal`, `kernels_ms_per_launch`, `path_stats`) for the dominant kernel of the timed steps."""
+    out = {}
+    names = abi.LR_KERNEL_NAMES
+    dom = max(range(abi.LR_K_COUNT), key=lambda k: acc["kernel_ms"][k] / max(acc["kernel_timed"][k], 1) * acc["kernel_launches"][k])
+    if acc["kernel_timed"][dom] == 0:
+        return out
+    avg_ms = acc["kernel_ms"][dom] / acc["kernel_timed"][dom]
+    one_launch = dom in (abi.LR_K_RESIDENT, abi.LR_K_PATH)          # one launch renders the whole frame, state never leaves the CU
+    pipeline = PIPELINE_NAMES.get(acc["pipeline"], "?")
+    s_per = acc["segments"] / max(acc["samples"], 1)
+    q_per = acc["shadow"] / max(acc["samples"], 1)
+    want = {"scene": scene_file, "width": W, "height": H, "spp": spp}
+
+    def kernel_entry(d, prefix):
+        for k, v in d.items():
+            if k.split("<")[0].startswith(prefix):
+                return k, v
+        return None, None
+
+    # ---- measured HBM bytes of the dominant kernel (committed FETCH_SIZE / WRITE_SIZE passes of this workload) ----
+    traffic, traffic_src = None, None
+    got = load_profile("traffic", cfg, want)
+    if got:
+        for k, v in got[1].items():
+            if k.startswith(f"k_{names[dom]}") and k.endswith("_hbm_bytes_per_launch"):
+                traffic, traffic_src = v, os.path.relpath(got[0], ROOT)
+    measured_gbps = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+
+    # ---- the VALU-issue roof, from the committed SQ counter passes of this workload ----
+    valu_block = None
+    gotp = load_profile("pmc", cfg, want)
+    if gotp:
+        kname, e = kernel_entry(gotp[1].get("kernels", {}), f"k_{names[dom]}")
+        if e and e.get("SQ_INSTS_VALU"):
+            valu, trans = e["SQ_INSTS_VALU"], e.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            gui, us = e.get("GRBM_GUI_ACTIVE"), e.get("avg_us_in_pmc_pass")
+            clock_ghz = gui / 8.0 / us / 1e3 if gui and us else NOMINAL_CLOCK_GHZ    # GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS section)
+            peak = N_SIMD * clock_ghz / VALU_CYCLES_PER_WAVE_INSTR                  # G wave-instructions / s
+            ach = (valu + trans) / (avg_ms * 1e-3) / 1e9                            # a transcendental occupies the issue port twice as long
+            wc = e.get("SQ_WAVE_CYCLES")
+            valu_block = {
+                "kernel": kname, "bound": "valu-issue", "achieved": round(ach, 2), "peak": round(peak, 2), "unit": "G wave-instr/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "measured_hbm_GBps": round(measured_gbps, 2) if measured_gbps else None,
+                "measured_hbm_frac": round(measured_gbps / HBM_PEAK_GBS, 5) if measured_gbps else None,
+                "avg_launch_ms": round(avg_ms, 5), "timed_launches": acc["kernel_timed"][dom],
+                "valu_wave_instr_per_launch": valu, "transcendental_per_launch": trans,
+                "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
+                "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
+                "wave_cycles_parked": round(e["SQ_WAIT_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None,
+                "wave_cycles_issue_stalled": round(e["SQ_WAIT_INST_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_INST_ANY") else None,
+                "note": "the kernel keeps path state in registers / LDS and the scene in caches, so HBM is not its roof (measured_hbm_frac); "
+                        "instructions per launch from the committed rocprofv3 pass of the same workload (deterministic per scene, film, spp "
+                        "up to the seed), duration from this run's HIP events; peak = 1024 SIMDs x clock / 2 cycles per wave64 instruction",
+            }
+
+    # ---- SURVEY 8(d) algorithmic bytes (nominal for the one-launch kernels): 224 B per closest-hit segment, 108 B per shadow
+    # ray, 16 B per child box tested (64-B 4-wide node), 48 B per primitive tested (1/64 when the rows come through the scalar
+    # cache once per wave), 12 B per film pixel.  Box / primitive counts from one short counted render (LR_FLAG_COUNT).
+    pc = desc.render_params(spp=min(32, spp), seed=77, integrator=integ, flags=abi.LR_FLAG_COUNT, path_slots=slots)
+    scene.render(pc, tiles, n_tiles, out=canvas)
+    sc = scene.stats()
+    flat = desc.desc.n_prims <= 32
+    queries = max(sc.segments + sc.shadow_rays, 1)
+    v_per_q = (sc.node_visits + sc.shadow_node_visits) / queries
+    t_per_q = (sc.prim_tests + sc.shadow_prim_tests) / queries
+    scene_bytes_per_q = NODE_BYTES_PER_CHILD_BOX * v_per_q + PRIM_BYTES * t_per_q / (64.0 if flat else 1.0)
+    bytes_per_sample = 224.0 * s_per + 108.0 * q_per + scene_bytes_per_q * (s_per + q_per) + 12.0 / spp
+    if one_launch:
+        units, unit_name = float(W) * H * spp, "camera samples"
+        bytes_per_launch = bytes_per_sample * units
+    elif dom == abi.LR_K_SHADOW:
+        units, unit_name = acc["shadow"] / max(acc["kernel_launches"][dom], 1), "shadow rays"
+        per_unit = 48.0 + 12.0 + 4.0 + NODE_BYTES_PER_CHILD_BOX * sc.shadow_node_visits / max(sc.shadow_rays, 1) + PRIM_BYTES * sc.shadow_prim_tests / max(sc.shadow_rays, 1) / (64.0 if flat else 1.0)
+        bytes_per_launch = per_unit * units
+    elif dom == abi.LR_K_SHADE:
+        units, unit_name = acc["segments"] / max(acc["kernel_launches"][dom], 1), "path vertices"
+        bytes_per_launch = (96.0 + 80.0 + 4.0 + 64.0) * units
+    else:
+        units, unit_name = acc["segments"] / max(acc["kernel_launches"][abi.LR_K_TRACE], 1), "segments"
+        per_unit = 32.0 + 8.0 + 4.0 + NODE_BYTES_PER_CHILD_BOX * sc.node_visits / max(sc.segments, 1) + PRIM_BYTES * sc.prim_tests / max(sc.segments, 1) / (64.0 if flat else 1.0)
+        bytes_per_launch = per_unit * units
+    nominal_gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    cache_served = nominal_gbps > HBM_PEAK_GBS
+    nominal = {
+        "kernel": f"k_{names[dom]}", "bound": "hbm", "nominal": True, "achieved": round(nominal_gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": None if cache_served else round(nominal_gbps / HBM_PEAK_GBS, 5), "cache_served": cache_served,
+        "algorithmic_bytes_per_launch": round(bytes_per_launch, 0), "bytes_per_camera_sample": round(bytes_per_sample, 1),
+        "units_per_launch": round(units, 1), "units": unit_name, "boxes_per_query": round(v_per_q, 2), "prim_tests_per_query": round(t_per_q, 2),
+        "traffic": traffic, "measured_hbm_GBps": round(measured_gbps, 2) if measured_gbps else None,
+        "note": "SURVEY 8(d): the bytes a wavefront design streams per unit (16 B per child box of the 64-B 4-wide node, 48 B per primitive). "
+                + ("They exceed what HBM can deliver in the launch time: they are served by registers, LDS and caches, so no HBM frac is claimed. "
+                   if cache_served else "")
+                + "`traffic` is what really crosses the HBM interface per launch",
+    }
+    if valu_block:
+        out["roofline"] = valu_block
+        out["roofline_hbm_nominal"] = nominal
+    elif not one_launch and measured_gbps:
+        out["roofline"] = {
+            "kernel": f"k_{names[dom]}", "bound": "hbm", "achieved": round(measured_gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(measured_gbps / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_ms": round(avg_ms, 5), "timed_launches": acc["kernel_timed"][dom],
+            "note": "streaming pipeline: MEASURED PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of this kernel per launch over this run's launch time",
+        }
+        out["roofline_hbm_nominal"] = nominal
+    else:
+        # no committed counter pass for this workload: only the nominal model can be printed, and it says so
+        nominal["avg_launch_ms"] = round(avg_ms, 5)
+        nominal["note"] = "NO committed PMC / traffic profile matches this workload -- nominal SURVEY 8(d) bytes only. " + nominal["note"]
+        out["roofline"] = nominal
+    out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
+                                    for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
+    out["path_stats"] = {"segments_per_sample": round(s_per, 3), "shadow_rays_per_sample": round(q_per, 3), "pipeline": pipeline,
+                         "path_slots": acc["path_slots"]}
+    return out
+
+
+def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_override, args, flags):
+    """One short single-GPU leg of another BASELINE config, after the headline's timed region: same lr_render path,
+    HIP-event launch times, its own roofline block."""
+    scene_file, W, H, stated_spp, integ, what, metric = CONFIGS[cfg]
+    spp = spp_override or stated_spp
+    desc = host.Description(os.path.join(ROOT, "scenes", scene_file))
+    desc.set_resolution(W, H)
+    integ_eff = desc.renderer.integrator if integ is None else integ
+    scene = device.Scene(desc, device=0)
+    tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, 0, 1)
+    canvas = np.zeros((H, W, 3), dtype=np.float32)
+    import torch
+    for i in range(warmup):
+        scene.render(desc.render_params(spp=spp, seed=1000 + i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)
+    acc = new_acc(abi)
+    torch.cuda.synchronize(0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        scene.render(desc.render_params(spp=spp, seed=i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)
+        add_stats(acc, scene.stats(), abi)
+    torch.cuda.synchronize(0)
+    elapsed = time.perf_counter() - t0
+    assert acc["samples"] == W * H * spp * steps, f"{cfg}: device finished {acc['samples']} samples, expected {W * H * spp * steps}"
+    assert np.isfinite(canvas).all(), f"{cfg}: non-finite film"
+    integ_name = "pt-direct" if integ_eff == abi.LR_INTEGRATOR_PT_DIRECT else "pt"
+    leg = {
+        "metric": metric, "value": round(float(W) * H * spp * steps / elapsed / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "config": {"workload": f"{cfg}: {scene_file} ({what}) {W}x{H} {spp} spp {integ_name}"
+                               + ("" if spp == stated_spp else f" [{spp} of the stated {stated_spp} spp: samples are i.i.d., the rate does not depend on spp]"),
+                   "baseline_config": cfg, "width": W, "height": H, "spp": spp, "stated_spp": stated_spp, "integrator": integ_name},
+    }
+    leg.update(roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, 0, flags))
+    scene.close()
+    return leg
 
 
 def main():
@@ -157,11 +344,13 @@ def main():
     dist = None
     host_group = None
     dev_group = None
+    barrier_kind = "device synchronize (single process)"
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # the env switch exercises the RCCL path on a 1-GPU box
     if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -169,6 +358,7 @@ def main():
         # brackets the timed region): an RCCL group when it comes up; a machine where it does not still gets its
         # numbers through the gloo barrier + device synchronisation.
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        barrier_kind = "gloo barrier + device synchronize"
         if "nccl" in args.backend:
             try:
                 import datetime
@@ -177,6 +367,7 @@ def main():
                 dist.all_reduce(probe, group=dev_group)
                 torch.cuda.synchronize(local_rank)
                 assert int(probe.item()) == world
+                barrier_kind = "RCCL all-reduce + device synchronize"
             except Exception as e:                                     # noqa: BLE001 -- report and fall back
                 print(f"[bench] rank {rank}: RCCL group unavailable ({type(e).__name__}: {e}); using the gloo barrier", file=sys.stderr, flush=True)
                 dev_group = None
@@ -188,7 +379,7 @@ def main():
     integ_eff = desc.renderer.integrator if integ is None else integ
     scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
-    flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0)
+    flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0) | (abi.LR_FLAG_RESIDENT if args.resident else 0)
     shared_film = multigpu.SharedFilm(W, H, args.tile, dist, dst=0, group=host_group)   # one film in /dev/shm for the ranks of this node
     canvas = shared_film.array
     barrier_buf = torch.zeros(1, device=f"cuda:{dev_index}") if (use_dist and dev_group is not None) else None
@@ -211,18 +402,11 @@ def main():
 
     for i in range(args.warmup):
         step(1000 + i)
-    acc = {"segments": 0, "shadow": 0, "samples": 0, "iterations": 0, "render_ms": 0.0,
-           "kernel_ms": [0.0] * abi.LR_K_COUNT, "kernel_timed": [0] * abi.LR_K_COUNT, "kernel_launches": [0] * abi.LR_K_COUNT}
-    path_slots = 0
+    acc = new_acc(abi)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        st = step(i)
-        acc["segments"] += st.segments; acc["shadow"] += st.shadow_rays; acc["samples"] += st.samples
-        acc["iterations"] += st.iterations; acc["render_ms"] += st.render_ms
-        path_slots = int(st.path_slots)
-        for k in range(abi.LR_K_COUNT):
-            acc["kernel_ms"][k] += st.kernel_ms[k]; acc["kernel_timed"][k] += st.kernel_timed[k]; acc["kernel_launches"][k] += st.kernel_launches[k]
+        add_stats(acc, step(i), abi)
     barrier()
     elapsed = time.perf_counter() - t0
     my_pixels = sum(tiles[i].w * tiles[i].h for i in range(n_tiles))
@@ -253,121 +437,30 @@ def main():
                 "workload": f"{args.config}: {scene_file} ({what}) {W}x{H} {spp} spp {integ_name}" + ("" if stated else " [NOT the stated config: overridden on the command line]"),
                 "baseline_config": args.config, "width": W, "height": H, "spp": spp, "integrator": integ_name, "tile": args.tile,
                 "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, film assembled in host shared memory, no collective on the data path",
-                "path_slots": path_slots,
+                "path_slots": acc["path_slots"], "pipeline": PIPELINE_NAMES.get(acc["pipeline"], "?"),
             },
             "rank_render_ms": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
+            "barrier": barrier_kind,
         }
-        # ---- roofline of the dominant kernel, N = 1 only ---------------------------------------------
-        names = abi.LR_KERNEL_NAMES
-        dom = max(range(abi.LR_K_COUNT), key=lambda k: acc["kernel_ms"][k] / max(acc["kernel_timed"][k], 1) * acc["kernel_launches"][k])
-        if world == 1 and acc["kernel_timed"][dom] > 0:
-            # DESIGN.md "algorithmic bytes" = SURVEY 8(d) with this build's record sizes, per camera sample:
-            #   224 B per closest-hit segment (ray 32 r + hit/list 16 w in trace; 96 r + 80 w of ray, hit, throughput,
-            #   radiance in shade), 108 B per shadow ray (48 w + 48 r + 12 rw), 32 B per child box tested, 48 B per
-            #   primitive tested (1/64 of that when the primitive rows come through the scalar cache once per wave),
-            #   12 B per film pixel.  Box / primitive counts come from one short counted render (LR_FLAG_COUNT).
-            pc = desc.render_params(spp=min(32, spp), seed=77, integrator=integ, flags=abi.LR_FLAG_COUNT, path_slots=args.slots)
-            scene.render(pc, tiles, n_tiles, out=canvas)
-            sc = scene.stats()
-            flat = desc.desc.n_prims <= 32
-            queries = max(sc.segments + sc.shadow_rays, 1)
-            v_per_q = (sc.node_visits + sc.shadow_node_visits) / queries
-            t_per_q = (sc.prim_tests + sc.shadow_prim_tests) / queries
-            s_per = acc["segments"] / acc["samples"]
-            q_per = acc["shadow"] / acc["samples"]
-            scene_bytes_per_q = 32.0 * v_per_q + 48.0 * t_per_q / (64.0 if flat else 1.0)
-            bytes_per_sample = 224.0 * s_per + 108.0 * q_per + scene_bytes_per_q * (s_per + q_per) + 12.0 / spp
-            avg_ms = acc["kernel_ms"][dom] / acc["kernel_timed"][dom]
-            resident = dom == abi.LR_K_RESIDENT
-            if resident:                        # one launch renders the whole frame
-                units = float(W) * H * spp
-                bytes_per_launch = bytes_per_sample * units
-                unit_name = "camera samples"
-            else:                               # streaming pipeline: the dominant kernel's own share per entry it processes
-                if dom == abi.LR_K_SHADOW:
-                    units = acc["shadow"] / max(acc["kernel_launches"][dom], 1)
-                    per_unit = 48.0 + 12.0 + 4.0 + 32.0 * sc.shadow_node_visits / max(sc.shadow_rays, 1) + 48.0 * sc.shadow_prim_tests / max(sc.shadow_rays, 1) / (64.0 if flat else 1.0)
-                    unit_name = "shadow rays"
-                elif dom == abi.LR_K_SHADE:
-                    units = (acc["segments"] + acc["samples"] * 0) / max(acc["kernel_launches"][dom], 1)
-                    per_unit = 96.0 + 80.0 + 4.0 + 64.0
-                    unit_name = "path vertices"
-                else:
-                    units = acc["segments"] / max(acc["kernel_launches"][abi.LR_K_TRACE], 1)
-                    per_unit = 32.0 + 8.0 + 4.0 + 32.0 * sc.node_visits / max(sc.segments, 1) + 48.0 * sc.prim_tests / max(sc.segments, 1) / (64.0 if flat else 1.0)
-                    unit_name = "segments"
-                bytes_per_launch = per_unit * units
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            want = {"scene": scene_file, "width": W, "height": H}
-            want.update({"spp": spp} if resident else {"path_slots": path_slots})
-            traffic, traffic_src = None, None
-            got = load_profile("traffic", args.config, want)
-            if got:
-                traffic = got[1].get(f"k_{names[dom]}_hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(got[0], ROOT)
-            out["roofline"] = {
-                "kernel": f"k_{names[dom]}", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 5), "units_per_launch": round(units, 1), "units": unit_name,
-                "algorithmic_bytes_per_launch": round(bytes_per_launch, 0), "bytes_per_camera_sample": round(bytes_per_sample, 1),
-                "boxes_per_query": round(v_per_q, 2), "prim_tests_per_query": round(t_per_q, 2),
-                "timed_launches": acc["kernel_timed"][dom],
-                # the MEASURED HBM rate next to the algorithmic one (PMC bytes of a profile of THIS workload over this run's launch time)
-                "measured_hbm_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None,
-                "measured_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                "nominal": bool(resident),
-                "note": ("NOMINAL: the algorithmic bytes are what a wavefront design streams per sample (SURVEY 8d); the resident kernel keeps "
-                         "them in LDS / the scalar cache and moves only `traffic` bytes through HBM, so this frac is not HBM saturation -- "
-                         "the roof this kernel is under is VALU issue, see roofline_valu") if resident else
-                        "streaming pipeline: path state moves through HBM / Infinity Cache every iteration; traffic = PMC bytes of this kernel per launch",
-            }
-            # ---- streaming pipeline: the bandwidth-bound stage beside the traversal (k_shade_all), MEASURED bytes over this run's launch time ----
-            if not resident and got and acc["kernel_timed"][abi.LR_K_SHADE]:
-                sh_bytes = got[1].get("k_shade_all_hbm_bytes_per_launch")
-                if sh_bytes:
-                    sh_ms = acc["kernel_ms"][abi.LR_K_SHADE] / acc["kernel_timed"][abi.LR_K_SHADE]
-                    alone = got[1].get("k_shade_all_hbm_GBps_in_pmc_pass")
-                    out["roofline_shade"] = {
-                        "kernel": "k_shade_all", "bound": "hbm", "achieved": round(sh_bytes / (sh_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(sh_bytes / (sh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": sh_bytes, "traffic_source": traffic_src,
-                        "avg_launch_ms": round(sh_ms, 5), "alone_GBps_in_pmc_pass": alone,
-                        "alone_frac": round(alone / HBM_PEAK_GBS, 5) if alone else None,
-                        "note": "PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the committed pass of this workload over this run's launch time; the launch "
-                                "shares the GPU with the other slot groups' traversal kernels -- alone (serialised profiler pass) it moves alone_GBps",
-                    }
-            # ---- the VALU-issue roof (what bounds k_resident): instructions from a committed PMC profile of this workload ----
-            gotp = load_profile("pmc", args.config, want)
-            if gotp:
-                kk = [k for k in gotp[1].get("kernels", {}) if k.split("<")[0] == f"k_{names[dom]}"]
-                if kk:
-                    e = gotp[1]["kernels"][kk[0]]
-                    valu, trans = e.get("SQ_INSTS_VALU"), e.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-                    gui, us = e.get("GRBM_GUI_ACTIVE"), e.get("avg_us_in_pmc_pass")
-                    if valu and gui and us:
-                        clock_ghz = gui / 8.0 / us / 1e3                  # GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS section)
-                        weighted = valu + trans                            # a transcendental occupies the issue port twice as long
-                        peak = N_SIMD * clock_ghz / VALU_CYCLES_PER_WAVE_INSTR          # G wave-instructions / s
-                        ach = weighted / (avg_ms * 1e-3) / 1e9
-                        wc = e.get("SQ_WAVE_CYCLES")
-                        out["roofline_valu"] = {
-                            "kernel": kk[0], "bound": "valu-issue", "achieved": round(ach, 2), "peak": round(peak, 2), "unit": "G wave-instr/s",
-                            "frac": round(ach / peak, 4), "valu_wave_instr_per_launch": valu, "transcendental_per_launch": trans,
-                            "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
-                            "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
-                            "wave_cycles_parked": round(e["SQ_WAIT_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None,
-                            "wave_cycles_issue_stalled": round(e["SQ_WAIT_INST_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_INST_ANY") else None,
-                            "note": "instructions per launch from the committed rocprofv3 pass of the same workload (deterministic per scene, "
-                                    "film, spp up to the seed), duration from this run's HIP events; peak = 1024 SIMDs x clock / 2 cycles",
-                        }
-            out["kernels_ms_per_launch"] = {names[k]: round(acc["kernel_ms"][k] / acc["kernel_timed"][k], 5)
-                                            for k in range(abi.LR_K_COUNT) if acc["kernel_timed"][k]}
-            out["path_stats"] = {"segments_per_sample": round(s_per, 3), "shadow_rays_per_sample": round(q_per, 3),
-                                 "pipeline": "resident" if resident else "streaming"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, W, H, integ, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        if world == 1:
+            out.update(roofline_blocks(abi, args.config, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, args.slots, flags))
     scene.close()
     shared_film.close()
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, W, H, integ, args.cpu_seconds)
+        default_run = stated and args.config == "c2" and not (args.streaming or args.resident)
+        if default_run and not args.no_other_configs:
+            # the other BASELINE configs, AFTER the headline's timed region (they do not touch `value`)
+            legs = {}
+            for cfg, steps, warmup, spp_o in OTHER_LEGS:
+                try:
+                    legs[cfg] = other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_o, args, abi.LR_FLAG_PROFILE)
+                except Exception as e:                                  # noqa: BLE001 -- e.g. generated assets missing: say so, keep the headline
+                    legs[cfg] = {"error": f"{type(e).__name__}: {e}"}
+            out["other_configs"] = legs
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
