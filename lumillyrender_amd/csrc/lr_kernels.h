@@ -194,7 +194,9 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - s.o.z) * s.iz;
     // t(q) is monotonic in q with the sign of 1/d: the ray enters a slab through the lower plane when it travels up the
     // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
-    const float bound = SHADOW ? s.dist + 2.0f * kEps : s.t;         // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far
+    // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far -- none below a node that
+    // holds a sliver triangle (lr_scene_create sets qb.z): its Moeller-Trumbore distance may land in front of its own box
+    const float bound = __float_as_uint(qb.z) != 0u ? inf : (SHADOW ? s.dist + 2.0f * kEps : s.t);
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);

@@ -249,11 +249,16 @@ __global__ void __launch_bounds__(kB) k_rs_scatter(const uint32_t* keys, const u
     for (int b = 0; b < 8; ++b) { uint64_t m = __ballot((d >> b) & 1u); same &= ((d >> b) & 1u) ? m : ~m; }
     const uint32_t below = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
     const uint32_t count = (uint32_t)__builtin_popcountll(same);
+    const int leader = same ? (int)__builtin_ctzll(same) : 0;      // lowest lane of this lane's digit group
     uint32_t pos = 0;
     for (uint32_t w = 0; w < kB / 64; ++w) {                        // waves take their positions in order: stable
-      if (wave == w && valid) {
-        pos = s_next[d] + below;
-        if (below == 0) s_next[d] += count;                         // one lane per digit group (all read before any adds: one wave instruction each)
+      if (wave == w) {
+        // ONE lane per digit group reads the group's base and advances it; the others get the base by shuffle -- no lane
+        // reads s_next[d] beside another lane's update of it, whatever the compiler schedules
+        uint32_t group_base = 0;
+        if (valid && below == 0) { group_base = s_next[d]; s_next[d] = group_base + count; }
+        group_base = (uint32_t)__shfl((int)group_base, leader, 64);
+        pos = group_base + below;
       }
       __syncthreads();
     }

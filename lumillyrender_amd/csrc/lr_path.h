@@ -45,6 +45,8 @@ struct WavePool { uint32_t r0, a0, r1, a1; };
 
 // ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
 struct PairHit { float t; int prim; float st; int sprim; bool occluded; };
+// the compare's own mask as the branch condition (the generic __ballot(int) builds lane data first: 2 VALU per use)
+LR_DEV uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 LR_DEV bool sphere_test_co(V3 co, float co2, float r2, V3 d, float* t_out) {     // sphere.rs:42-55 given co = o - c and |co|^2
   float cod = dot(co, d);
@@ -81,13 +83,13 @@ LR_DEV void flat_test_pair(float4 q0, float4 q1, float4 q2, V3 o, V3 d, V3 sd, f
     float invB = rcp_exact_mid(detB);
     float uB = dot(tv, pvB) * invB;
     bool okB = has_sh & bool(!(__builtin_fabsf(detB) < kEps)) & bool(!(uB < 0.0f)) & bool(!(uB > 1.0f));
-    if (__ballot(okA | okB) != 0) {
+    if (lane_mask(okA | okB) != 0) {
       V3 qv = cross(tv, e1);
       float vA = dot(d, qv) * invA;
       okA = okA & bool(!(vA < 0.0f)) & bool(!(uA + vA > 1.0f));
       float vB = dot(sd, qv) * invB;
       okB = okB & bool(!(vB < 0.0f)) & bool(!(uB + vB > 1.0f));
-      if (__ballot(okA | okB) != 0) {
+      if (lane_mask(okA | okB) != 0) {
         float eq = dot(e2, qv);
         tA = eq * invA;
         hitA = okA & bool(!(tA < kEps));
@@ -380,7 +382,7 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
     const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - o.x) * s.ix;
     const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - o.y) * s.iy;
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - o.z) * s.iz;
-    const float bound = s.shadow ? s.dist + 2.0f * kEps : s.t;       // the light's distance (+ the visibility window), or the closest hit so far
+    const float bound = __float_as_uint(qb.z) != 0u ? inf : (s.shadow ? s.dist + 2.0f * kEps : s.t);   // as trav_node
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);

@@ -54,6 +54,7 @@ struct DevBuf {
   void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
 };
 
+constexpr double kSliverInvSin = 8.0;   // triangles with sin(angle at p0) < 1/8 are exempt from distance culling
 constexpr int kEventPool = 1024;      // timed launches per kernel type per render
 constexpr int kProfileStride = 2;     // time every 2nd iteration when LR_FLAG_PROFILE is set
 
@@ -118,6 +119,11 @@ namespace {
 struct Wide4Builder {
   const std::vector<float4>& in;
   std::vector<float4>& out;
+  // leaf_flag[k] != 0: the primitive at leaf position k is a triangle whose Moeller-Trumbore distance is ill-conditioned for
+  // every direction (a sliver at its first vertex, see pack_scene).  A node with such a leaf anywhere below it is stored with
+  // its "no distance culling" word set: bvh.rs:131-141 tests every leaf whose box the ray touches, however far behind the
+  // closest hit so far it begins, and only for these triangles can the reported distance land in front of their own box.
+  const std::vector<uint8_t>* leaf_flag = nullptr;
   struct Cand { float lo[3], hi[3]; int ref; };
   static float area(const Cand& c) {
     float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
@@ -128,8 +134,9 @@ struct Wide4Builder {
     two[0] = Cand{{x.x, y.x, z.x}, {x.y, y.y, z.y}, __builtin_bit_cast(int, c.x)};
     two[1] = Cand{{x.z, y.z, z.z}, {x.w, y.w, z.w}, __builtin_bit_cast(int, c.y)};
   }
-  int build(int node, int* need_out) {
+  int build(int node, int* need_out, bool* flagged_out = nullptr) {
     const size_t me = out.size() / kNodeRows;
+    bool flagged = false;
     out.resize(out.size() + kNodeRows, make_float4(0, 0, 0, 0));
     Cand c[4]; int n = 2;
     children(node, c);
@@ -146,8 +153,14 @@ struct Wide4Builder {
       int ref = kEmptyChild;
       if (k < n) {
         ref = c[k].ref;
-        if (ref >= 0) { int sub = 0; ref = build(ref, &sub); need = std::max(need, n - 1 + sub); }
-        else need = std::max(need, n - 1);
+        if (ref >= 0) { int sub = 0; bool f = false; ref = build(ref, &sub, &f); flagged = flagged || f; need = std::max(need, n - 1 + sub); }
+        else {
+          need = std::max(need, n - 1);
+          if (leaf_flag && ref != kEmptyChild) {
+            const uint32_t enc = (uint32_t)~ref, first = enc >> 3, count = enc & 7u;
+            for (uint32_t q = first; q < first + count && q < leaf_flag->size(); ++q) flagged = flagged || (*leaf_flag)[q] != 0;
+          }
+        }
       }
       refs[k] = ref;
     }
@@ -183,9 +196,10 @@ struct Wide4Builder {
     auto fb = [](uint32_t u) { return __builtin_bit_cast(float, u); };
     out[me * kNodeRows + 0] = make_float4(org[0], org[1], org[2], fb(ebits));
     out[me * kNodeRows + 1] = make_float4(fb(qlo[0]), fb(qlo[1]), fb(qlo[2]), fb(qhi[0]));
-    out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), 0.0f, 0.0f);
+    out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), fb(flagged ? 1u : 0u), 0.0f);
     out[me * kNodeRows + 3] = make_float4(fb((uint32_t)refs[0]), fb((uint32_t)refs[1]), fb((uint32_t)refs[2]), fb((uint32_t)refs[3]));
     *need_out = need;
+    if (flagged_out) *flagged_out = flagged;
     return (int)me;
   }
 };
@@ -217,6 +231,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   std::vector<float4> shade((size_t)np * 4), emit;
   std::vector<uint8_t> qid((size_t)np);
   std::vector<float> area((size_t)np);
+  std::vector<uint8_t> sliver((size_t)np, 0);
   for (int q = 0; q < kNumShadeQueues - 1; ++q) s.mat_present[q] = false;
   for (int i = 0; i < np; ++i) {
     const LrPrimitive& p = d.prims[i];
@@ -233,6 +248,14 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       shade[4 * i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
       area[i] = nrm * 0.5f;
+      // triangle.rs:69-100 divides by det = e1 . (d x e2) = |e1||e2| sin(phi) cos(theta): with a small angle phi between the edges
+      // at p0 the distance t = (e2 . qv) / det carries a relative error of ~eps / (sin(phi) cos(theta)) for EVERY direction, enough
+      // to report the hit in front of the triangle's own (padded) box.  Such triangles are exempt from distance culling.
+      {
+        const double cx = (double)e1[1] * e2[2] - (double)e1[2] * e2[1], cy = (double)e1[2] * e2[0] - (double)e1[0] * e2[2], cz = (double)e1[0] * e2[1] - (double)e1[1] * e2[0];
+        const double sinphi_l1l2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+        sliver[i] = !(sinphi_l1l2 * kSliverInvSin >= l1 * l2) ? 1 : 0;     // sin(phi) < 1 / kSliverInvSin (also degenerate / NaN)
+      }
     } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
       shade[4 * i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
       area[i] = 4.0f * kPi * (p.v[3] * p.v[3]);
@@ -358,13 +381,35 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       HIP_OK(hipMemcpyAsync(nodes.data(), s.nodes.p, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
       HIP_OK(hipStreamSynchronize(s.stream));
     }
+    // leaf position -> sliver flag (leaf order: the description's permutation, or the ids the device builder left in the rows)
+    std::vector<uint8_t> leaf_flag((size_t)std::max(np, 1), 0);
+    bool any_sliver = false;
+    for (int i = 0; i < np; ++i) any_sliver = any_sliver || sliver[i];
+    if (any_sliver) {
+      if (built_on_device) {
+        std::vector<float4> rows((size_t)np * 3);
+        HIP_OK(hipMemcpyAsync(rows.data(), s.prims.p, rows.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipStreamSynchronize(s.stream));
+        for (int k = 0; k < np; ++k) { uint32_t id = __builtin_bit_cast(uint32_t, rows[3 * (size_t)k].w) & 0x7fffffffu; if (id < (uint32_t)np) leaf_flag[k] = sliver[id]; }
+      } else if (!device_bvh) {
+        for (int k = 0; k < np; ++k) leaf_flag[k] = sliver[d.bvh_prim_order[k]];
+      } else if (np == 1) leaf_flag[0] = sliver[0];
+    }
     std::vector<float4> wide;
     wide.reserve(nodes.size());
     int need = 0;
-    Wide4Builder{nodes, wide}.build(0, &need);
+    Wide4Builder w4{nodes, wide};
+    w4.leaf_flag = any_sliver ? &leaf_flag : nullptr;
+    w4.build(0, &need);
     if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
     s.stack_depth = need + 1;
-    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d\n", nodes.size() / 4, wide.size() / kNodeRows, kNodeRows * 16, need);
+    if (std::getenv("LR_DEBUG")) {
+      size_t n_sliver = 0, n_nocull = 0;
+      for (int i = 0; i < np; ++i) n_sliver += sliver[i];
+      for (size_t k = 0; k < wide.size() / kNodeRows; ++k) n_nocull += __builtin_bit_cast(uint32_t, wide[k * kNodeRows + 2].z) != 0u;
+      std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d; %zu sliver triangles, %zu nodes without distance culling\n",
+                   nodes.size() / 4, wide.size() / kNodeRows, kNodeRows * 16, need, n_sliver, n_nocull);
+    }
     s.nodes.upload(wide, s.stream);
     if (!built_on_device) s.prims.upload(prims, s.stream);
   }
@@ -479,17 +524,21 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   prefix.push_back((uint32_t)npix64);
   if (npix64 > (uint64_t)W * (uint64_t)H) fail(LR_EINVAL, "tiles overlap (more tile pixels than film pixels)");
   {
-    // the header promises disjoint tiles: a pixel in two tiles would be rendered twice and resolved twice.  Sweep over
-    // the tiles sorted by first row; only tiles whose row ranges intersect are compared.
-    std::vector<int> ord(tl.size());
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
-    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return tl[a].y < tl[b].y || (tl[a].y == tl[b].y && tl[a].x < tl[b].x); });
-    for (size_t i = 0; i < ord.size(); ++i) {
-      const int4 a = tl[ord[i]];
-      for (size_t j = i + 1; j < ord.size(); ++j) {
-        const int4 b = tl[ord[j]];
-        if (b.y >= a.y + a.w) break;                                // int4 {x0, y0, w, h}: .z = w, .w = h
-        if (b.x < a.x + a.z && a.x < b.x + b.z) fail(LR_EINVAL, "tiles overlap");
+    // the header promises disjoint tiles: a pixel in two tiles would be rendered twice and resolved twice.  One occupancy bit per
+    // film pixel, tested and set a 64-bit word at a time: linear in the pixels the tiles cover, whatever their shapes (a
+    // per-pixel or per-scanline job list costs what a few large tiles cost)
+    const size_t row_words = ((size_t)W + 63) / 64;
+    std::vector<uint64_t> occ(row_words * (size_t)H, 0);
+    for (const int4& t : tl) {                                        // int4 {x0, y0, w, h}
+      const int x0 = t.x, x1 = t.x + t.z;
+      for (int y = t.y; y < t.y + t.w; ++y) {
+        uint64_t* row = occ.data() + (size_t)y * row_words;
+        for (int wi = x0 >> 6; wi <= (x1 - 1) >> 6; ++wi) {
+          const int lo = std::max(x0, wi << 6) & 63, hi = std::min(x1, (wi + 1) << 6) - (wi << 6);     // bits [lo, hi) of this word
+          const uint64_t m = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+          if (row[wi] & m) fail(LR_EINVAL, "tiles overlap");
+          row[wi] |= m;
+        }
       }
     }
   }

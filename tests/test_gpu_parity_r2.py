@@ -133,9 +133,9 @@ def test_tree_equals_brute_force_under_random_transforms(dev, seed):
     """tools/fuzz_traversal.py's scenes: the mesh scaled 1e-3..1e3, stretched up to 50:1, rotated, moved up to 1e4 sizes
     off the origin, the camera up to ~1e4 sizes away, rays from anywhere between surface and camera, grazing and
     axis-parallel through vertices.  Host SAH tree and device LBVH must both return brute force's primitive and distance
-    bits for every ray whose brute-force hit lies inside the bounds of its own primitive (a
-    Moeller-Trumbore distance that lands outside the triangle's box -- edge-on slivers seen from far away -- is the one
-    thing distance culling cannot reproduce; seeds 4, 17, 79 and 121 contain such rays and they are checked to be that)."""
+    bits for EVERY ray (a Moeller-Trumbore distance that lands outside the triangle's own box -- edge-on
+    slivers seen from far away -- is what distance culling cannot reproduce; the tree therefore does not cull by distance above
+    such triangles.  Seeds 4, 17, 79 and 121 contain such rays)."""
     if not _generated_assets():
         pytest.skip("generated assets missing (run __graft_entry__.build())")
     import importlib.util
@@ -143,7 +143,9 @@ def test_tree_equals_brute_force_under_random_transforms(dev, seed):
     ft = importlib.util.module_from_spec(spec); spec.loader.exec_module(ft)
     bad, excused, hit, n_prims, *_ = ft.run(seed, 100_000)
     assert bad == [0, 0], f"seed {seed}: {bad} rays differ from brute force inside their primitive's own bounds"
-    assert excused < 0.002 * 200_000
+    # round 3: nodes above a sliver triangle (sin of the angle at p0 < 1/8) are exempt from distance culling, so the rays
+    # round 2 had to excuse (seeds 4, 17, 79, 121) now get brute force's answer too: bvh.rs:131-141 holds for every ray
+    assert excused == 0, f"seed {seed}: {excused} rays whose brute-force hit lies outside its own primitive's box still differ"
 
 
 @pytest.mark.parametrize("name", ["cbox-spheres.toml", "brdf-row.toml"])
