@@ -181,6 +181,16 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
     s_per = acc["segments"] / max(acc["samples"], 1)
     q_per = acc["shadow"] / max(acc["samples"], 1)
     want = {"scene": scene_file, "width": W, "height": H, "spp": spp}
+    scale, scaled_from = 1.0, None
+    if load_profile("pmc", cfg, want) is None:
+        # no counter pass at this spp: one of the SAME scene and film at another spp, counts scaled by the spp ratio (camera samples are
+        # i.i.d. and every per-launch count is linear in their number) -- labelled as such
+        loose = {"scene": scene_file, "width": W, "height": H}
+        alt = load_profile("pmc", cfg, loose)
+        if alt and alt[1].get("workload", {}).get("spp"):
+            scaled_from = int(alt[1]["workload"]["spp"])
+            scale = spp / float(scaled_from)
+            want = dict(loose, spp=scaled_from)
 
     def kernel_entry(d, prefix):
         for k, v in d.items():
@@ -194,7 +204,7 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
     if got:
         for k, v in got[1].items():
             if k.startswith(f"k_{names[dom]}") and k.endswith("_hbm_bytes_per_launch"):
-                traffic, traffic_src = v, os.path.relpath(got[0], ROOT)
+                traffic, traffic_src = v * scale, os.path.relpath(got[0], ROOT)
     measured_gbps = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
 
     # ---- the VALU-issue roof, from the committed SQ counter passes of this workload ----
@@ -203,7 +213,7 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
     if gotp:
         kname, e = kernel_entry(gotp[1].get("kernels", {}), f"k_{names[dom]}")
         if e and e.get("SQ_INSTS_VALU"):
-            valu, trans = e["SQ_INSTS_VALU"], e.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            valu, trans = e["SQ_INSTS_VALU"] * scale, e.get("SQ_INSTS_VALU_TRANS_F32", 0.0) * scale
             gui, us = e.get("GRBM_GUI_ACTIVE"), e.get("avg_us_in_pmc_pass")
             clock_ghz = gui / 8.0 / us / 1e3 if gui and us else NOMINAL_CLOCK_GHZ    # GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS section)
             peak = N_SIMD * clock_ghz / VALU_CYCLES_PER_WAVE_INSTR                  # G wave-instructions / s
@@ -217,7 +227,8 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
                 "avg_launch_ms": round(avg_ms, 5), "timed_launches": acc["kernel_timed"][dom],
                 "valu_wave_instr_per_launch": valu, "transcendental_per_launch": trans,
                 "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
-                "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
+                "counts_scaled_from_spp": scaled_from,
+                "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] * scale / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
                 "wave_cycles_parked": round(e["SQ_WAIT_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None,
                 "wave_cycles_issue_stalled": round(e["SQ_WAIT_INST_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_INST_ANY") else None,
                 "note": "the kernel keeps path state in registers / LDS and the scene in caches, so HBM is not its roof (measured_hbm_frac); "

@@ -6,7 +6,7 @@
 #   passes), SQ issue counters (the VALU roof), L2 / L1 counters, and the bench.py JSON line with those attached.
 # rocprofv3 gets the python program directly after `--` (no env / bash hop: the profiler has initialised the GPU).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
 CFGS=${*:-c2 c3 c4 c5}
 OUT=$PWD/gpurun_out/$TAG
