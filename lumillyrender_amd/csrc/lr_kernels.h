@@ -1374,7 +1374,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevState st, DevP
 // MASK = the BSDF types that can occur (a scene's materials); bit kQMiss is implied.
 // 5 waves per SIMD = 96 VGPRs (32-96 B of scratch): not for this kernel's own occupancy but for what fits BESIDE it -- one
 // of its waves leaves room for five 80-VGPR traversal waves of another slot group on the same SIMD, two for four.  At 4 waves
-// the allocation follows the code (112 or 120 registers) and a 4-register change cost the mesh scene 8 % (DESIGN.md 6.3).
+// the allocation follows the code (112 or 120 registers) and a 4-register change cost the mesh scene 8 % (DESIGN.md 6.4).
 #ifndef LR_DENSE_WAVES
 #define LR_DENSE_WAVES 5
 #endif

@@ -575,7 +575,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // fused: one persistent launch in which a lane carries its path in registers (lr_path.h); flat scenes
   bool fused = false;
   {
-    // default for flat scenes with ONE BSDF (the headline class: +10 % over the resident pipeline, DESIGN.md 6.2); with several
+    // default for flat scenes with ONE BSDF (the headline class: +10 % over the resident pipeline, DESIGN.md 6.1); with several
     // BSDFs in a wave the per-lane material dispatch loses to the resident pipeline's per-BSDF lists (brdf row: 7.8 vs 9.6 G/s)
     const char* pe = std::getenv("LR_PIPELINE");
     const bool forced = (rp_in.flags & LR_FLAG_FUSED) || (pe && std::strcmp(pe, "fused") == 0);
@@ -728,7 +728,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const void* kdense = dense_variant == 0 ? (const void*)k_shade_all<1u> : (dense_variant == 1 ? (const void*)k_shade_all<9u> : (const void*)k_shade_all<31u>);
     constexpr int kMaxGroups = 3;
     // two slot groups on two streams; three when an iteration is only trace + shade (no shadow stage): measured +4 % on the
-    // 100k-triangle pt scene, -3 % on the pt-direct one (DESIGN.md section 6.3)
+    // 100k-triangle pt scene, -3 % on the pt-direct one (DESIGN.md section 6.4)
     const bool has_shadow_stage = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
     int G = (!count && n_seg >= 64) ? ((dense_shade && !has_shadow_stage && n_seg >= 96) ? 3 : 2) : 1;
     if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
