@@ -44,6 +44,9 @@ LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int
 struct WavePool { uint32_t r0, a0, r1, a1; };
 
 // ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
+#ifndef LR_PAIR_BALLOTS
+#define LR_PAIR_BALLOTS 2             // wave-level skips of the v and t stages when no lane of the wave needs them (never change a result)
+#endif
 struct PairHit { float t; int prim; float st; int sprim; bool occluded; };
 // the compare's own mask as the branch condition (the generic __ballot(int) builds lane data first: 2 VALU per use)
 LR_DEV uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
@@ -83,13 +86,19 @@ LR_DEV void flat_test_pair(float4 q0, float4 q1, float4 q2, V3 o, V3 d, V3 sd, f
     float invB = rcp_exact_mid(detB);
     float uB = dot(tv, pvB) * invB;
     bool okB = has_sh & bool(!(__builtin_fabsf(detB) < kEps)) & bool(!(uB < 0.0f)) & bool(!(uB > 1.0f));
-    if (lane_mask(okA | okB) != 0) {
+#if LR_PAIR_BALLOTS >= 2
+    if (lane_mask(okA | okB) != 0)
+#endif
+    {
       V3 qv = cross(tv, e1);
       float vA = dot(d, qv) * invA;
       okA = okA & bool(!(vA < 0.0f)) & bool(!(uA + vA > 1.0f));
       float vB = dot(sd, qv) * invB;
       okB = okB & bool(!(vB < 0.0f)) & bool(!(uB + vB > 1.0f));
-      if (lane_mask(okA | okB) != 0) {
+#if LR_PAIR_BALLOTS >= 1
+      if (lane_mask(okA | okB) != 0)
+#endif
+      {
         float eq = dot(e2, qv);
         tA = eq * invA;
         hitA = okA & bool(!(tA < kEps));

@@ -688,6 +688,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     L.run(LR_K_PATH, [&] {
       if (s.dev.n_flat > 0) {
         if (mt_mask == 1u) hipLaunchKernelGGL(k_path_flat<1u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
+        else if (only == 9u) hipLaunchKernelGGL(k_path_flat<9u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
         else hipLaunchKernelGGL(k_path_flat<31u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
       } else {
         if (lds > 48 * 1024) {

@@ -233,7 +233,7 @@ def many_emitter_scene(t, extra_spheres=0):
 def test_many_emitters_and_a_sphere_light(dev, oracle, extra):
     """objects.rs:37-51 with 15 emitters (device: binary search over the running area sums), one of them a sphere
     (sphere.rs:79-84 sampled as a light, its emission seen through shadow rays that end on a sphere).  extra = 0 keeps
-    the scene flat (27 primitives), extra = 24 pushes it onto the tree; resident and streaming pipelines both."""
+    the scene flat (27 primitives), extra = 24 pushes it onto the tree; every pipeline (the fused one stages the emitter rows in LDS)."""
     from lumillyrender_amd import abi
     desc = load("cbox-spheres.toml", 44, 40, text_edit=lambda t: many_emitter_scene(t, extra))
     assert desc.desc.n_prims == 10 + 14 + 1 + 2 + extra
@@ -249,7 +249,7 @@ def test_many_emitters_and_a_sphere_light(dev, oracle, extra):
     assert set(np.unique(got)) == set(range(15))
     for integ in (abi.LR_INTEGRATOR_PT_DIRECT, abi.LR_INTEGRATOR_PT):
         ref, ost = oracle.render(desc, desc.render_params(spp=16, seed=12, integrator=integ), with_stats=True)
-        for flags in (0, abi.LR_FLAG_STREAMING, abi.LR_FLAG_RESIDENT):
+        for flags in (0, abi.LR_FLAG_STREAMING, abi.LR_FLAG_RESIDENT, abi.LR_FLAG_FUSED):
             img = scene.render(desc.render_params(spp=16, seed=12, integrator=integ, flags=flags))
             st = scene.stats()
             assert (st.samples, st.segments, st.shadow_rays) == (ost.samples, ost.segments, ost.shadow_rays), (integ, flags)
@@ -277,7 +277,7 @@ def test_depth_limit_halving(dev, oracle, depth, limit):
         assert (r.depth, r.depth_limit) == (depth, limit)
         scene = dev.Scene(desc)
         ref, ost = oracle.render(desc, desc.render_params(spp=32, seed=3, integrator=integ), with_stats=True)
-        for flags in (0, abi.LR_FLAG_STREAMING):
+        for flags in (0, abi.LR_FLAG_STREAMING, abi.LR_FLAG_FUSED):
             img = scene.render(desc.render_params(spp=32, seed=3, integrator=integ, flags=flags))
             st = scene.stats()
             assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays), (name, integ, flags)
