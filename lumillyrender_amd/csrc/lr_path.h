@@ -44,23 +44,26 @@ LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int
 struct WavePool { uint32_t r0, a0, r1, a1; };
 
 // ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
+// Wave-level skips of the v and t stages of the pair test when no lane of the wave needs them (they never change a result):
+// 2 = both, 1 = the t stage only, 0 = none.  With 64 unrelated rays per wave some lane almost always passes, so the skips
+// save nothing and their branches cost: measured on configs[1] 5452 / 5500 / 5554 Msamples/s for 2 / 1 / 0.
 #ifndef LR_PAIR_BALLOTS
-#define LR_PAIR_BALLOTS 2             // wave-level skips of the v and t stages when no lane of the wave needs them (never change a result)
+#define LR_PAIR_BALLOTS 0
 #endif
 struct PairHit { float t; int prim; float st; int sprim; bool occluded; };
 // the compare's own mask as the branch condition (the generic __ballot(int) builds lane data first: 2 VALU per use)
 LR_DEV uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 LR_DEV bool sphere_test_co(V3 co, float co2, float r2, V3 d, float* t_out) {     // sphere.rs:42-55 given co = o - c and |co|^2
+  // every lane runs every operation (no early return: a wave of 64 unrelated rays never skips as a whole); the same
+  // comparisons decide on the same values, so a miss is a miss exactly where sphere.rs:46,51 return None
   float cod = dot(co, d);
   float det = cod * cod - co2 + r2;
-  if (det <= 0.0f) return false;
   float sq = __builtin_sqrtf(det);
   float t1 = -cod - sq;
   float t2 = -cod + sq;
-  if (t1 < kEps && t2 < kEps) return false;
   *t_out = t1 > kEps ? t1 : t2;
-  return true;
+  return bool(!(det <= 0.0f)) & bool(!(bool(t1 < kEps) & bool(t2 < kEps)));
 }
 
 LR_DEV void flat_test_pair(float4 q0, float4 q1, float4 q2, V3 o, V3 d, V3 sd, float sdist, bool has_sh, PairHit& r) {
