@@ -475,21 +475,25 @@ LR_DEV float checker(float u, float v) {                               // lamber
   float cu = up ? u300 : 300.0f - u300, cv = vp ? v300 : 300.0f - v300;
   return checker_level(lu, lv, su, sv, cu, cv);
 }
+// The three GGX terms are radiance-only (they end up in the BRDF value and in the pdf that divides it, never in a direction or
+// a decision), so their divisions and the square root are the 1-ulp hardware forms (see rcp_r): 15 IEEE sequences of ~10
+// instructions each per GGX vertex otherwise.  The half vector and the sampled direction (material_sample) stay exact.
+LR_DEV float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
 LR_DEV float ggx_g(float alpha, V3 v, V3 n) {                          // ggx.rs:27-32
   float a2 = alpha * alpha;
   float c = dot(v, n);
-  float tan = 1.0f / (c * c) - 1.0f;
-  return 2.0f / (1.0f + __builtin_sqrtf(1.0f + a2 * tan * tan));
+  float tan = rcp_r(c * c) - 1.0f;
+  return 2.0f * rcp_r(1.0f + sqrt_r(1.0f + a2 * tan * tan));
 }
 LR_DEV float ggx_ndf(float alpha, V3 mm, V3 n) {                       // ggx.rs:34-39
   float a2 = alpha * alpha;
   float mdn = dot(mm, n);
   float x = (a2 - 1.0f) * mdn * mdn + 1.0f;
-  return a2 / (kPi * x * x);
+  return a2 * rcp_r(kPi * x * x);
 }
 LR_DEV float ggx_fresnel(float ior, V3 in_, V3 mm) {                   // ggx.rs:41-47
   float nnn = 1.0f - ior, nnp = 1.0f + ior;
-  float f_0 = (nnn * nnn) / (nnp * nnp);
+  float f_0 = (nnn * nnn) * rcp_r(nnp * nnp);
   float c = dot(in_, mm);
   float c1 = 1.0f - c;
   float c2 = c1 * c1, c4 = c2 * c2;                                    // powi(5) = c1 * (c1^2)^2
@@ -507,9 +511,12 @@ LR_DEV float fresnel_exact(float n1, float n2, V3 out_, V3 in_, V3 on) {        
   return (a * a + b * b) / 2.0f;
 }
 
+// lam_pre: the Lambert value of this vertex, computed once by the caller (it depends on the position only and a vertex asks
+// for it twice: for the light sample and for the BSDF sample)
 template <int MT>
-LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
+LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos, const V3* lam_pre = nullptr) {
   if (MT == LR_MAT_LAMBERT) {                                          // lambert.rs:32-35
+    if (lam_pre) return *lam_pre;
     float g = checker(pos.x, pos.z) * kInvPi;
     return mcolor(m) * g;
   } else if (MT == LR_MAT_PHONG) {                                     // phong.rs:37-45
@@ -640,9 +647,9 @@ constexpr int kMtDyn = 8;
   if ((MASK & 8u) && __ballot(mt == 3)) { if (mt == 3) { CALL(3) } }                \
   if ((MASK & 16u) && __ballot(mt == 4)) { if (mt == 4) { CALL(4) } }
 template <uint32_t MASK>
-LR_DEV V3 material_brdf_dyn(int mt, const Mat& m, V3 out_, V3 in_, V3 n, V3 pos) {
+LR_DEV V3 material_brdf_dyn(int mt, const Mat& m, V3 out_, V3 in_, V3 n, V3 pos, const V3* lam_pre = nullptr) {
   V3 r = v3(0.0f, 0.0f, 0.0f);
-#define LR_CALL(K) r = material_brdf<K>(m, out_, in_, n, pos);
+#define LR_CALL(K) r = material_brdf<K>(m, out_, in_, n, pos, lam_pre);
   LR_MT_CASES(LR_CALL)
 #undef LR_CALL
   return r;
@@ -667,17 +674,27 @@ LR_DEV V3 material_coef_dyn(int mt, const Mat& m, V3 out_, V3 n, float fly_dista
 // ------------------------------------------------------------------------------------------
 LR_DEV V3 arr3(const float* a) { return v3(a[0], a[1], a[2]); }
 
+#ifdef LR_FORCE_CAMERA                                                 // diagnostic builds: what a camera-specialised kernel would cost
+#define LR_CAM_TYPE(c) LR_FORCE_CAMERA
+#else
+#define LR_CAM_TYPE(c) (c).type
+#endif
+#ifdef LR_FORCE_SKY
+#define LR_SKY_TYPE(sc) LR_FORCE_SKY
+#else
+#define LR_SKY_TYPE(sc) (sc).sky_type
+#endif
 LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* o_out, V3* d_out, float* g_out) {
   V3 position = arr3(c.position), right = arr3(c.right), up = arr3(c.up);
   V3 aperture_position = arr3(c.aperture_position);
-  if (c.type == LR_CAMERA_IDEAL_PINHOLE) {                             // camera.rs:64-115
+  if (LR_CAM_TYPE(c) == LR_CAMERA_IDEAL_PINHOLE) {                     // camera.rs:64-115
     float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
     float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
     V3 point = position - right * px + up * py;
     *o_out = aperture_position;
     *d_out = normalize(aperture_position - point);
     *g_out = 1.0f;
-  } else if (c.type == LR_CAMERA_THIN_LENS) {                          // camera.rs:411-476
+  } else if (LR_CAM_TYPE(c) == LR_CAMERA_THIN_LENS) {                  // camera.rs:411-476
     V3 forward = arr3(c.forward);
     float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
     float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
@@ -693,8 +710,8 @@ LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* 
     *d_out = normalize(aperture_position + object_plane - apoint);
     V3 dir = normalize(apoint - point);                                // geometry_term :446-455
     float cos_term = dot(dir, forward);
-    float dd = c.aperture_sensor_distance / cos_term;
-    *g_out = cos_term * cos_term / (dd * dd);
+    float dd = c.aperture_sensor_distance * rcp_r(cos_term);          // the geometry term only scales the sample's radiance: 1-ulp forms (rcp_r)
+    *g_out = cos_term * cos_term * rcp_r(dd * dd);
   } else {                                                             // camera.rs:168-188
     float p = ((float)x + d.v[0]) / (float)c.res_w * kPi * 2.0f;
     float t = ((float)y + d.v[1]) / (float)c.res_h * kPi;
@@ -723,7 +740,7 @@ LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
   return (y * width + x) % all;
 }
 LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
-  if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
+  if (LR_SKY_TYPE(sc) == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
   return v3(sc.texels[sky_texel_index(sc, dir)]);
 }
 
@@ -1171,10 +1188,12 @@ struct VertexIn { float4 ro, rd, th, ra; float2 h; float4 sh, m0, m1, m2; };
 
 // MT = the BSDF type, kQMiss, or kMtDyn: type per lane (`mt`, one of MASK's bits), see material_*_dyn
 // ST = where the vertex's outputs go: DevState (rows of the slot in HBM or LDS) or the lane's own registers (lr_path.h)
-template <int MT, uint32_t MASK = 0, class ST>
+// NEE = 1 / 0: the integrator is known when the kernel is instantiated (pt-direct / pt) and the other one's code -- and its
+// registers -- are not compiled in; -1: read it from rp (the kernels that serve both)
+template <int MT, uint32_t MASK = 0, int NEE = -1, class ST>
 LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& rp, uint32_t slot, const VertexIn& in, int mt = MT) {
   VertexOut out; out.finished = false; out.has_shadow = false; out.sky_fetch = false;
-  const bool nee_mode = rp.integrator == LR_INTEGRATOR_PT_DIRECT;
+  const bool nee_mode = NEE < 0 ? rp.integrator == LR_INTEGRATOR_PT_DIRECT : NEE != 0;
   const float4 ro = in.ro, rd = in.rd, th = in.th, ra = in.ra;
   int depth = __float_as_int(ro.w);
   out.pixel = __float_as_uint(th.w); out.sample = __float_as_uint(ra.w);
@@ -1206,6 +1225,16 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
     if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
       out.finished = true;
     } else {
+      // lambert.rs:32-35 depends on the vertex position only: one evaluation serves the light sample and the BSDF sample
+      V3 lam_val = v3(0.0f, 0.0f, 0.0f);
+      const V3* lam_pre = nullptr;
+      if constexpr (NEE != 0) {                                      // without a light sample the value is asked for once anyway
+        if constexpr (MT == LR_MAT_LAMBERT) { lam_val = material_brdf<LR_MAT_LAMBERT>(m, out_, out_, nrm, pos); lam_pre = &lam_val; }
+        else if constexpr (MT == kMtDyn && (MASK & 1u) != 0u) {
+          if (__ballot(mt == LR_MAT_LAMBERT) != 0) { if (mt == LR_MAT_LAMBERT) lam_val = material_brdf<LR_MAT_LAMBERT>(m, out_, out_, nrm, pos); }
+          lam_pre = &lam_val;
+        }
+      }
       // ---- direct light (scene.rs:104-151); the occlusion test itself is the shadow stage ----
       if (nee_mode && !(sqr_norm(emission) > 0.0f) && sc.emission_area > 0.0f) {
         V3 lp; float lpdf;
@@ -1218,8 +1247,8 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
         float point_cos = dot(dir, point_normal);
         if (point_cos > 0.0f) {
           V3 brdf;
-          if constexpr (MT == kMtDyn) brdf = material_brdf_dyn<MASK>(mt, m, out_, dir, point_normal, pos);
-          else brdf = material_brdf<MT>(m, out_, dir, point_normal, pos);
+          if constexpr (MT == kMtDyn) brdf = material_brdf_dyn<MASK>(mt, m, out_, dir, point_normal, pos, lam_pre);
+          else brdf = material_brdf<MT>(m, out_, dir, point_normal, pos, lam_pre);
           V3 W = T * (brdf * (point_cos * rcp_r(d2 * lpdf * p)));
           st.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, dist);
           st.sh_w[slot] = make_float4(W.x, W.y, W.z, 0.0f);
@@ -1232,11 +1261,11 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
       V3 brdf, coef;
       if constexpr (MT == kMtDyn) {
         material_sample_dyn<MASK>(mt, m, out_, nrm, d2r.v, &in_, &pdf);
-        brdf = material_brdf_dyn<MASK>(mt, m, out_, in_, nrm, pos);
+        brdf = material_brdf_dyn<MASK>(mt, m, out_, in_, nrm, pos, lam_pre);
         coef = material_coef_dyn<MASK>(mt, m, out_, nrm, t);
       } else {
         material_sample<MT>(m, out_, nrm, d2r.v, &in_, &pdf);
-        brdf = material_brdf<MT>(m, out_, in_, nrm, pos);
+        brdf = material_brdf<MT>(m, out_, in_, nrm, pos, lam_pre);
         coef = material_coef<MT>(m, out_, nrm, t);
       }
       float c = dot(in_, nrm);

@@ -243,7 +243,7 @@ LR_DEV void path_finish(const DevScene& sc, const DevState& st, const DevParams&
 
 // One vertex for the lanes whose ray is done: hit -> scene.rs:153-193, miss -> sky.  `rec(prim, row)` reads the 64-B shading
 // record.  Leaves the next ray (and possibly a connection to test) in ls, or c.finished with the final radiance in ls.rad.
-template <uint32_t MTS, class LS, class RecFn>
+template <uint32_t MTS, int NEE = -1, class LS, class RecFn>
 LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl& c, bool live, float t, int prim, RecFn rec, uint32_t& n_sky) {
   const bool hitv = live && prim >= 0, miss = live && prim < 0;
   if (hitv) {
@@ -254,9 +254,9 @@ LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl
     VertexOut v;
     if constexpr ((MTS & (MTS - 1u)) == 0u) {
       constexpr int K = MTS == 1u ? 0 : (MTS == 2u ? 1 : (MTS == 4u ? 2 : (MTS == 8u ? 3 : 4)));
-      v = shade_vertex_core<K>(sc, ls, rp, 0u, in);
+      v = shade_vertex_core<K, 0u, NEE>(sc, ls, rp, 0u, in);
     } else {
-      v = shade_vertex_core<kMtDyn, MTS>(sc, ls, rp, 0u, in, (int)__float_as_uint(in.m0.w));
+      v = shade_vertex_core<kMtDyn, MTS, NEE>(sc, ls, rp, 0u, in, (int)__float_as_uint(in.m0.w));
     }
     c.has_sh = v.has_shadow;
     if (v.finished) { c.finished = true; ls.rad.v = make_float4(v.L.x, v.L.y, v.L.z, in.ra.w); }
@@ -382,6 +382,7 @@ LR_DEV bool ptrav_pop(const DevScene& sc, PTrav& s, const uint32_t* stk_n) {
   return false;
 }
 // one 4-wide node (trav_node): boxes only prune, so fused / approximate arithmetic is allowed here
+template <bool CONN>                                              // CONN = false: no lane ever walks a connection (integrator pt)
 LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
   const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
   float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
@@ -394,7 +395,7 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
     const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - o.x) * s.ix;
     const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - o.y) * s.iy;
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - o.z) * s.iz;
-    const float bound = __float_as_uint(qb.z) != 0u ? inf : (s.shadow ? s.dist + 2.0f * kEps : s.t);   // as trav_node
+    const float bound = __float_as_uint(qb.z) != 0u ? inf : ((CONN && s.shadow) ? s.dist + 2.0f * kEps : s.t);   // as trav_node
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
@@ -424,6 +425,7 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
   return true;
 }
 // one leaf (trav_leaf): the primitive tests decide, exact arithmetic
+template <bool CONN>
 LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n) {
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
@@ -438,7 +440,7 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, s.d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), o, s.d, &t);
     if (!hit) continue;
-    if (s.shadow) {
+    if (CONN && s.shadow) {
       float diff = t - s.dist;
       if (diff < -kEps) { s.occluded = true; return false; }
       if (diff > kEps) continue;
@@ -447,22 +449,31 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
   }
   return ptrav_pop(sc, s, stk_n);
 }
+template <bool CONN>
 LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go) {
 #pragma unroll 1
   for (int it = 0; it < kDescendBurst; ++it) {
     bool nm = go && s.cur >= 0;
     if (__ballot(nm) == 0) break;
-    if (nm) go = ptrav_node(sc, s, o, stk_n);
+    if (nm) go = ptrav_node<CONN>(sc, s, o, stk_n);
   }
-  if (go && s.cur < 0) go = ptrav_leaf(sc, s, o, stk_n);
+  if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, o, stk_n);
 }
 
 #ifndef LR_PATHT_WAVES
 #define LR_PATHT_WAVES 6
 #endif
+#ifndef LR_PATHT_WAVES_PT
+#define LR_PATHT_WAVES_PT 7
+#endif
+// waves per SIMD of k_path_tree: the pt instantiation carries no connection code and fits 72 VGPRs (48 B of scratch): 7 waves
+// render the 100k-triangle scene 1.8 % faster than 6 (8 do not fit the LDS); the pt-direct one is best at 6 (80 VGPRs)
+LR_DEV constexpr int path_tree_waves_c(bool nee) { return nee ? LR_PATHT_WAVES : LR_PATHT_WAVES_PT; }
+inline int path_tree_waves(bool nee) { return nee ? LR_PATHT_WAVES : LR_PATHT_WAVES_PT; }
 
-template <uint32_t MTS>
-__global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene sc, DevState st, DevParams rp) {
+// NEE: the integrator is pt-direct (connections are produced, walked and resolved) or pt (none of that code exists)
+template <uint32_t MTS, bool NEE>
+__global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(DevScene sc, DevState st, DevParams rp) {
   extern __shared__ uint32_t lds[];                                  // traversal stack: sc.stack_lds entries per lane
   __shared__ RowVec s_acc[kBlock];
   __shared__ uint32_t s_end[kBlock];
@@ -491,7 +502,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene s
     }
     // ================= retire point (converged) =================
     // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
-    {
+    if constexpr (NEE) {
       const bool fs = has && fin && tr.shadow;
       if (__ballot(fs) != 0) {
         if (fs) {
@@ -507,7 +518,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene s
     {
       const bool fm = has && fin;                                      // (a) left only closest-hit walks with fin set
       if (__ballot(fm) != 0) {
-        path_vertex<MTS>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, n_sky);
+        path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, n_sky);
         if (fm) { has = false; fin = false; }
       }
     }
@@ -518,9 +529,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene s
     {
       const bool start = !has && __float_as_int(ls.ray_o.v.w) >= 0;
       n_seg += (uint32_t)__builtin_popcountll(__ballot(start));
-      n_shq += (uint32_t)__builtin_popcountll(__ballot(start && c.has_sh));
+      if constexpr (NEE) n_shq += (uint32_t)__builtin_popcountll(__ballot(start && c.has_sh));
       if (start) {
-        if (c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v), ls.sh_d.v.w, true);
+        if (NEE && c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v), ls.sh_d.v.w, true);
         else ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
         has = true; fin = false;
       }
@@ -532,7 +543,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATHT_WAVES) k_path_tree(DevScene s
     const int thresh = live_n / 2 < kRefillBelow ? live_n / 2 : kRefillBelow;
     const V3 o = v3(ls.ray_o.v);
     bool go = has && !fin;
-    do { ptrav_burst(sc, tr, o, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+    do { ptrav_burst<NEE>(sc, tr, o, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
     fin = has && !go;
   }
   if (lane_id() == 0) {

@@ -592,7 +592,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(32u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * RB) : stream_slots);
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * RB));   // every workgroup must be resident: no grid-stride
-  if (fused) n_slots = (uint32_t)(s.n_cus * (s.dev.n_flat > 0 ? LR_PATH_WAVES : LR_PATHT_WAVES) * kBlock);   // one path per lane of every resident wave
+  if (fused) n_slots = (uint32_t)(s.n_cus * (s.dev.n_flat > 0 ? LR_PATH_WAVES : path_tree_waves(rp_in.integrator == LR_INTEGRATOR_PT_DIRECT)) * kBlock);   // one path per lane of every resident wave
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -691,14 +691,14 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         else if (only == 9u) hipLaunchKernelGGL(k_path_flat<9u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
         else hipLaunchKernelGGL(k_path_flat<31u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
       } else {
-        if (lds > 48 * 1024) {
-          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<9u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          HIP_OK(hipFuncSetAttribute((const void*)k_path_tree<31u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (only == 1u) hipLaunchKernelGGL(k_path_tree<1u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
-        else if (only == 9u) hipLaunchKernelGGL(k_path_tree<9u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
-        else hipLaunchKernelGGL(k_path_tree<31u>, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
+        const bool nee_k = dp.integrator == LR_INTEGRATOR_PT_DIRECT;     // (a pt-direct scene without emitters runs the NEE kernel: the branch is then never taken)
+        auto launch_tree = [&](auto kernel) {
+          if (lds > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
+        };
+        if (only == 1u) { if (nee_k) launch_tree(k_path_tree<1u, true>); else launch_tree(k_path_tree<1u, false>); }
+        else if (only == 9u) { if (nee_k) launch_tree(k_path_tree<9u, true>); else launch_tree(k_path_tree<9u, false>); }
+        else { if (nee_k) launch_tree(k_path_tree<31u, true>); else launch_tree(k_path_tree<31u, false>); }
       }
     });
     S.iterations = 1;
