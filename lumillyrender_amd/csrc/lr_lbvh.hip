@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(kB) k_rs_scatter(const uint32_t* keys, const u
 #endif
 constexpr int kPlocR = LR_PLOC_R;
 constexpr float kTAabb = 1.0f, kTTri = 2.0f;
+constexpr int kPlocMaxHeight = 88;
 
 struct PlocNodes {                       // one entry per created node (n - 1 in all)
   int2* child;                           // cluster references of the two children
@@ -607,9 +608,15 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
     LB_OK(hipStreamSynchronize(st));
     if (created != n_nodes) { err = "PLOC created " + std::to_string(created) + " nodes for " + std::to_string(n) + " primitives"; return LR_EDEVICE; }
     float ms = 0.0f; LB_OK(hipEventElapsedTime(&ms, e0, e1));
-    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] ploc: %d primitives, %d iterations, %.3f ms on the device\n", n, iters, ms);
-    *height_out = h < 1 ? 1 : h; *ms_out = ms;
-    return LR_OK;
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] ploc: %d primitives, %d iterations, height %d, %.3f ms on the device\n", n, iters, h, ms);
+    // Needle-shaped primitives (a mesh stretched 40:1) make area-driven merging chain up: heights of ~100 were seen (fuzz seeds
+    // 515, 529, 669, 711).  The traversal stack is sized for <= 95; such an input gets the radix tree below instead, whose
+    // height is bounded by the key length.
+    if (h <= kPlocMaxHeight) {
+      *height_out = h < 1 ? 1 : h; *ms_out = ms;
+      return LR_OK;
+    }
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] ploc: tree too deep (%d), falling back to the radix tree\n", h);
   }
   LB_OK(hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), st));
   LB_OK(hipMemsetAsync(height, 0, (size_t)n * sizeof(int), st));
