@@ -1,13 +1,15 @@
-// lr_kernels.h -- the wavefront path-tracing kernels for gfx950 (wave64, 256-thread workgroups).
+// lr_kernels.h -- device functions of the path (primitive tests, 4-wide node step, BSDFs, cameras, sky, emitter sampling, the
+// vertex of scene.rs:153-193) and the kernels of two of the three pipelines that run them; the third, default one -- the
+// FUSED pipeline, one persistent launch in which a lane carries its path in registers -- is lr_path.h.
 //
-// One iteration of the render loop is   trace -> shade -> shadow.   The shade stage is k_shade_all (one launch over the
+// STREAMING pipeline (state in HBM, one launch per stage and iteration; since round 3 the counting / reference pipeline):
+// one iteration of the render loop is   trace -> shade -> shadow.   The shade stage is k_shade_all (one launch over the
 // slots themselves, every class of vertex under its lane mask) or, with LR_DENSE=0, one k_shade<bsdf> launch per BSDF
 // present plus the miss/sky launch over the lists k_trace then writes.  Paths never leave their slot: a path that ends regenerates
 // the next camera sample of its work item in place, so every slot is live until the work-item
 // dispenser runs dry ("persistent" path slots; workgroups are grid-strided over them).
-// Two pipelines run these stages over the same device functions: the STREAMING kernels below (state in
-// HBM, one launch per stage and iteration) and k_resident (state in LDS, the stages as phases of one
-// launch; chosen for flat scenes and shallow trees, see its header further down).
+// RESIDENT pipeline (k_resident: state in LDS, the stages as phases of one launch; flat scenes with several BSDFs, see its
+// header further down).
 //
 //   k_generate   camera.rs:64-115 / :411-476 / :168-188   first camera sample of every slot
 //   k_trace      bvh.rs:130-141 + aabb.rs:74-92 + triangle.rs:69-100 + sphere.rs:42-63
@@ -674,27 +676,17 @@ LR_DEV V3 material_coef_dyn(int mt, const Mat& m, V3 out_, V3 n, float fly_dista
 // ------------------------------------------------------------------------------------------
 LR_DEV V3 arr3(const float* a) { return v3(a[0], a[1], a[2]); }
 
-#ifdef LR_FORCE_CAMERA                                                 // diagnostic builds: what a camera-specialised kernel would cost
-#define LR_CAM_TYPE(c) LR_FORCE_CAMERA
-#else
-#define LR_CAM_TYPE(c) (c).type
-#endif
-#ifdef LR_FORCE_SKY
-#define LR_SKY_TYPE(sc) LR_FORCE_SKY
-#else
-#define LR_SKY_TYPE(sc) (sc).sky_type
-#endif
 LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* o_out, V3* d_out, float* g_out) {
   V3 position = arr3(c.position), right = arr3(c.right), up = arr3(c.up);
   V3 aperture_position = arr3(c.aperture_position);
-  if (LR_CAM_TYPE(c) == LR_CAMERA_IDEAL_PINHOLE) {                     // camera.rs:64-115
+  if (c.type == LR_CAMERA_IDEAL_PINHOLE) {                             // camera.rs:64-115
     float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
     float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
     V3 point = position - right * px + up * py;
     *o_out = aperture_position;
     *d_out = normalize(aperture_position - point);
     *g_out = 1.0f;
-  } else if (LR_CAM_TYPE(c) == LR_CAMERA_THIN_LENS) {                  // camera.rs:411-476
+  } else if (c.type == LR_CAMERA_THIN_LENS) {                          // camera.rs:411-476
     V3 forward = arr3(c.forward);
     float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
     float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
@@ -740,7 +732,7 @@ LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
   return (y * width + x) % all;
 }
 LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
-  if (LR_SKY_TYPE(sc) == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
+  if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
   return v3(sc.texels[sky_texel_index(sc, dir)]);
 }
 
