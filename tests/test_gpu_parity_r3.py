@@ -185,6 +185,25 @@ def test_full_size_properties_of_configs_3_to_5(dev, name, W, H):
     scene.close()
 
 
+@pytest.mark.parametrize("name,W,H", FULL_SIZE[1:])
+def test_full_size_film_is_pipeline_independent(dev, name, W, H):
+    """Configs 4 and 5 at full film size (2 spp): the fused kernel (one launch, ~1800 workgroups that draw work items from
+    per-wave pools in whatever order they get to them) and the streaming pipeline (millions of slots, three launches per
+    iteration) produce the same film bit for bit and the same counters -- the film depends on neither scheduling nor pipeline."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    from lumillyrender_amd import abi
+    desc = load(name, W, H)
+    scene = dev.Scene(desc)
+    a = scene.render(desc.render_params(spp=2, seed=33, flags=abi.LR_FLAG_FUSED))
+    sa = scene.stats()
+    b = scene.render(desc.render_params(spp=2, seed=33, flags=abi.LR_FLAG_STREAMING))
+    sb = scene.stats()
+    assert sa.pipeline == 2 and sb.pipeline == 0 and _counters(sa) == _counters(sb) and sa.samples == W * H * 2
+    assert np.array_equal(a, b)
+    scene.close()
+
+
 def test_bench_rccl_barrier_branch_runs(tmp_path):
     """bench.py's N > 1 branch -- gloo default group, RCCL sub-group, all-reduce barrier around the timed region -- executed
     on this box's one GPU (BENCH_FORCE_DIST=1, world 1), so that the driver's N-GPU run is not its first execution; the JSON
