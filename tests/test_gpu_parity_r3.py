@@ -248,3 +248,19 @@ def test_device_builders_prune_only(dev, oracle, monkeypatch, builder):
         q = dsc.render_params(spp=6, seed=9)                       # (flat scenes test every primitive; the tree is still built, collapsed and validated by lr_scene_create)
         assert np.array_equal(a.render(q), b.render(q)), name
         a.close(); b.close()
+
+
+def test_ploc_falls_back_on_needle_meshes(dev, monkeypatch, capfd):
+    """A mesh stretched 40:1 (tools/fuzz_traversal.py seed 515) makes PLOC's area-driven merging chain up to a height of ~100;
+    the builder then discards that tree for the radix tree, whose height the key length bounds, instead of refusing the scene.
+    Either way the tree only prunes: every ray gets brute force's primitive and distance bits."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_traversal", os.path.join(ROOT, "tools", "fuzz_traversal.py"))
+    ft = importlib.util.module_from_spec(spec); spec.loader.exec_module(ft)
+    monkeypatch.setenv("LR_DEBUG", "1")
+    bad, excused, hit, n_prims, *_ = ft.run(515, 60_000)
+    err = capfd.readouterr().err
+    assert "falling back to the radix tree" in err, err[-600:]
+    assert bad == [0, 0] and excused == 0 and hit > 0.3
