@@ -51,8 +51,7 @@ struct WavePool { uint32_t r0, a0, r1, a1; };
 #define LR_PAIR_BALLOTS 0
 #endif
 struct PairHit { float t; int prim; float st; int sprim; bool occluded; };
-// the compare's own mask as the branch condition (the generic __ballot(int) builds lane data first: 2 VALU per use)
-LR_DEV uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+LR_DEV uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }    // the compare's own mask as a branch condition
 
 LR_DEV bool sphere_test_co(V3 co, float co2, float r2, V3 d, float* t_out) {     // sphere.rs:42-55 given co = o - c and |co|^2
   // every lane runs every operation (no early return: a wave of 64 unrelated rays never skips as a whole); the same
@@ -165,7 +164,8 @@ struct PathCtl {
 constexpr int kRecStride = 5;          // float4 rows per staged shading record: 80 B, so 16 records start in 16 different bank groups
 
 // main.rs:92-121 for the lanes whose sample ended (or that have no item yet): fold into the chunk sum, draw the next work
-// item from the wave's pool, start the next camera sample.  Whole (converged) wave.  Returns false for a lane that retired.
+// item from the wave's pool, start the next camera sample.  Whole (converged) wave.  A lane that finds pool and dispenser
+// empty retires: its ray_o.w (depth) becomes -1 and it takes no further part.
 template <class LS>
 LR_DEV void path_finish(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, WavePool& pool,
                         uint32_t& pend, bool& pending, bool& dry, LdsRow* s_acc, uint32_t* s_end, uint32_t& n_done) {
