@@ -315,8 +315,15 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
   return res;
 }
 
+// wave-level skips of the v and t stages of the flat triangle test (2 = both, 1 = t only, 0 = none): as in the pair loop of
+// lr_path.h they almost never skip with 64 unrelated rays per wave and their branches cost a little (config 3: 10 340 -> 10 370)
 #ifndef LR_FLAT_BALLOTS
-#define LR_FLAT_BALLOTS 2
+#define LR_FLAT_BALLOTS 0
+#endif
+// the shadow loop may stop when every lane of the wave already knows it is occluded: it almost never happens with 64 unrelated
+// connections, and the test is a ballot + branch per primitive
+#ifndef LR_FLAT_SHADOW_EXIT
+#define LR_FLAT_SHADOW_EXIT 0
 #endif
 typedef float RowVec __attribute__((ext_vector_type(4)));
 typedef RowVec __attribute__((address_space(4))) ConstRow;
@@ -367,7 +374,11 @@ LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, T
   bool better = hit & bool(t < res.t);                   // rows come in primitive-id order: the first of equal hits is the lowest id
   res.t = better ? t : res.t;
   res.prim = better ? id : res.prim;
+#if LR_FLAT_SHADOW_EXIT
   return SHADOW && __ballot(!res.occluded) == 0;
+#else
+  return false;
+#endif
 }
 
 // Small scenes (n_flat = number of primitives when <= kFlatMax, else 0): the SAH says a tree over a
