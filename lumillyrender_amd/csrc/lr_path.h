@@ -424,6 +424,22 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
   }
   return true;
 }
+// triangle.rs:69-100 without early returns: every lane runs every operation and the same comparisons decide on the same values
+#ifndef LR_LEAF_BRANCHFREE
+#define LR_LEAF_BRANCHFREE 1
+#endif
+LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
+  V3 pv = cross(d, e2);
+  float det = dot(e1, pv);
+  float invdet = rcp_exact_mid(det);
+  V3 tv = o - p0;
+  float u = dot(tv, pv) * invdet;
+  V3 qv = cross(tv, e1);
+  float v = dot(d, qv) * invdet;
+  float t = dot(e2, qv) * invdet;
+  *t_out = t;
+  return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
+}
 // one leaf (trav_leaf): the primitive tests decide, exact arithmetic
 template <bool CONN>
 LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n) {
@@ -437,8 +453,13 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
     uint32_t idw = __float_as_uint(q0.w);
     int id = (int)(idw & 0x7fffffffu);
     float t; bool hit;
+#if LR_LEAF_BRANCHFREE
+    if (idw >> 31) { V3 co = o - v3(q0); hit = sphere_test_co(co, sqr_norm(co), q1.y, s.d, &t); }
+    else hit = tri_test_bf(v3(q0), v3(q1), v3(q2), o, s.d, &t);
+#else
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, s.d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), o, s.d, &t);
+#endif
     if (!hit) continue;
     if (CONN && s.shadow) {
       float diff = t - s.dist;
