@@ -36,6 +36,7 @@
 namespace lr {
 
 constexpr int kBlock = 256;            // 4 waves of 64
+constexpr int kStackLdsFused = 10;     // ... by k_path_tree, whose LDS also holds the spare camera samples (lr_path.h)
 constexpr int kStackLdsMax = 16;       // traversal stack entries per lane kept in LDS by the streaming kernels; near-first order rarely goes deeper
                                        // (12 / 16 / 25 entries render the 100k-triangle configs at the same speed), the rest of the worst case spills
 constexpr int kNodeRows = 4;         // float4 rows per 4-wide node (64 B)

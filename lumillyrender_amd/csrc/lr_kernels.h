@@ -34,7 +34,19 @@ namespace lr {
 // segment in LDS: one global atomic per wave on a shared word costs ~12 ns and serialises (the first
 // version of these kernels spent >90 % of its time there), an LDS atomic does not.
 // ------------------------------------------------------------------------------------------
-LR_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (every kernel here is launched with one-dimensional workgroups of whole waves: the lane id is a mask of a live register, not
+//  a loop-invariant mbcnt result that the allocator parks in scratch)
+LR_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+// A loop-invariant value, made opaque at the point of use: whatever is computed from it (an integer reciprocal, a float
+// conversion, an LDS address) is computed THERE instead of once at kernel entry.  In the persistent kernels everything hoisted
+// to the entry lives across the whole loop, and what does not fit the registers is reloaded from scratch -- a round trip
+// through the vector-memory path (3000+ cycles under a tree walk's load) where ten instructions would have done.
+template <class T> LR_DEV T fresh_s(T v) { asm volatile("" : "+s"(v)); return v; }     // wave-uniform value
+LR_DEV uint32_t fresh_v(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// count `mask`'s lanes into a workgroup statistic (converged wave): one LDS atomic without return, no register kept
+LR_DEV void stat_count(uint32_t* lds_stat, uint64_t mask) {
+  if (mask != 0 && lane_id() == 0) atomicAdd(lds_stat, (uint32_t)__builtin_popcountll(mask));
+}
 LR_DEV uint32_t rank_in_mask(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -687,26 +699,34 @@ LR_DEV V3 material_coef_dyn(int mt, const Mat& m, V3 out_, V3 n, float fly_dista
 // ------------------------------------------------------------------------------------------
 LR_DEV V3 arr3(const float* a) { return v3(a[0], a[1], a[2]); }
 
-LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* o_out, V3* d_out, float* g_out) {
+// the ray origin of a camera sample, given the aperture point's coordinates in the lens plane (thin lens only)
+LR_DEV V3 camera_origin(const DevCamera& c, float apx, float apy) {
+  V3 aperture_position = arr3(c.aperture_position);
+  if (c.type == LR_CAMERA_THIN_LENS) return aperture_position + arr3(c.right) * apx + arr3(c.up) * apy;
+  return aperture_position;
+}
+LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* o_out, V3* d_out, float* g_out, float* lens_out = nullptr) {
   V3 position = arr3(c.position), right = arr3(c.right), up = arr3(c.up);
   V3 aperture_position = arr3(c.aperture_position);
+  const int res_w = fresh_s(c.res_w), res_h = fresh_s(c.res_h);
   if (c.type == LR_CAMERA_IDEAL_PINHOLE) {                             // camera.rs:64-115
-    float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
-    float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
+    float px = ((((float)x + d.v[0]) / (float)res_w) - 0.5f) * c.sensor_w;
+    float py = ((((float)y + d.v[1]) / (float)res_h) - 0.5f) * c.sensor_h;
     V3 point = position - right * px + up * py;
     *o_out = aperture_position;
     *d_out = normalize(aperture_position - point);
     *g_out = 1.0f;
   } else if (c.type == LR_CAMERA_THIN_LENS) {                          // camera.rs:411-476
     V3 forward = arr3(c.forward);
-    float px = ((((float)x + d.v[0]) / (float)c.res_w) - 0.5f) * c.sensor_w;
-    float py = ((((float)y + d.v[1]) / (float)c.res_h) - 0.5f) * c.sensor_h;
+    float px = ((((float)x + d.v[0]) / (float)res_w) - 0.5f) * c.sensor_w;
+    float py = ((((float)y + d.v[1]) / (float)res_h) - 0.5f) * c.sensor_h;
     V3 point = position - right * px + up * py;
     float au = 2.0f * kPi * d.v[2];
     float av = __builtin_sqrtf(d.v[3]) * c.aperture_radius;
     float s1, c1; det_sincos(au, &s1, &c1);
     float apx = c1 * av, apy = s1 * av;
     V3 apoint = aperture_position + right * apx + up * apy;
+    if (lens_out) { lens_out[0] = apx; lens_out[1] = apy; }
     V3 sensor_center = aperture_position - point;
     V3 object_plane = sensor_center * (c.focus_distance / dot(sensor_center, forward));
     *o_out = apoint;
@@ -716,8 +736,8 @@ LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* 
     float dd = c.aperture_sensor_distance * rcp_r(cos_term);          // the geometry term only scales the sample's radiance: 1-ulp forms (rcp_r)
     *g_out = cos_term * cos_term * rcp_r(dd * dd);
   } else {                                                             // camera.rs:168-188
-    float p = ((float)x + d.v[0]) / (float)c.res_w * kPi * 2.0f;
-    float t = ((float)y + d.v[1]) / (float)c.res_h * kPi;
+    float p = ((float)x + d.v[0]) / (float)res_w * kPi * 2.0f;
+    float t = ((float)y + d.v[1]) / (float)res_h * kPi;
     float sp, cp, st, ct; det_sincos(p, &sp, &cp); det_sincos(t, &st, &ct);
     *o_out = aperture_position;
     *d_out = v3(st * cp, st * sp, ct);
@@ -736,7 +756,7 @@ LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
   float u = uu >= 0.0f ? det_fmod_pos(uu, 1.0f) : -det_fmod_pos(-uu, 1.0f);
   float vv = theta / kPi;
   float v = vv >= 0.0f ? det_fmod_pos(vv, 1.0f) : -det_fmod_pos(-vv, 1.0f);
-  uint32_t height = (uint32_t)sc.sky_h, width = height * 2u;
+  uint32_t height = (uint32_t)fresh_s(sc.sky_h), width = height * 2u;
   uint64_t all = (uint64_t)width * height;
   float fx = __builtin_floorf((float)width * u), fy = __builtin_floorf((float)height * v);
   uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates

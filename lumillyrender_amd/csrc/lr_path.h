@@ -40,8 +40,12 @@ LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int
   else return sc.emit[i];
 }
 
-// ---- wave-level work-item pool: two ranges of reserved item ids in scalar registers + one refill in flight ----
-struct WavePool { uint32_t r0, a0, r1, a1; };
+// LR_DIAG build: wave-uniform phase counters of k_path_tree (calls, lanes, cycles), printed by lr_render
+struct PathDiag { unsigned long long cyc_total, cyc_resolve, n_resolve, l_resolve, cyc_vertex, n_vertex, l_vertex, cyc_finish, n_finish, l_finish,
+                  cyc_walk, walks, walk_lanes, node_steps, node_lanes, cyc_node, leaf_steps, leaf_lanes, cyc_leaf, leaf_prims, n_batch, l_batch, n_forced, cyc_batch; };
+
+// ---- wave-level work-item pool: a range of reserved item ids in scalar registers ----
+struct WavePool { uint32_t r0, a0; bool dry; };   // next reserved item, how many are left, the dispenser has run out
 
 // ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
 // Wave-level skips of the v and t stages of the pair test when no lane of the wave needs them (they never change a result):
@@ -163,88 +167,152 @@ struct PathCtl {
 #endif
 constexpr int kRecStride = 5;          // float4 rows per staged shading record: 80 B, so 16 records start in 16 different bank groups
 
-// main.rs:92-121 for the lanes whose sample ended (or that have no item yet): fold into the chunk sum, draw the next work
-// item from the wave's pool, start the next camera sample.  Whole (converged) wave.  A lane that finds pool and dispenser
-// empty retires: its ray_o.w (depth) becomes -1 and it takes no further part.
+// ---- spare camera samples: the finish stage as a dense batch ---------------------------------------------------------
+// Paths of a wave end a few at a time (8 of 64 lanes per retire point on the 100k-triangle scene), and fold + next work item +
+// camera sample at that density was 17 % of the frame.  So a lane keeps the NEXT sample of its sequence ready in LDS: the
+// camera ray's direction and weight (16 B), pixel, work item and sample number (12 B) and, for the thin lens, the point on
+// the aperture (8 B) -- the traversal stack gives up 6 of its 16 LDS entries for them (measured: free down to 10).  A lane
+// whose path ends folds its radiance and installs its spare (path_consume: a few instructions); spares are produced for every
+// lane that lacks one as soon as LR_SPARE_BATCH lanes do, or at once when a path ends without one (path_spare_batch: the pool
+// draw, the RNG block and camera.rs sample(), now at 20+ of 64 lanes).  Which lane renders which work item changes; a work
+// item's samples are still folded in order by one lane, so the film does not.  (First built with the spares in global memory,
+// three 16-B rows: a round trip through the vector-memory path of a tree scene costs 3000+ cycles, -5 %.)
+#ifndef LR_SPARE_BATCH
+#define LR_SPARE_BATCH 24
+#endif
+constexpr uint32_t kNoItem = 0xffffffffu;     // spare of a lane that found pool and dispenser empty: consuming it retires the lane
+struct SpareLds {
+  LdsRow* acc; uint32_t* end;                 // the sample in flight: chunk sum + work item, chunk end
+  LdsRow* dir;                                // the spare: camera ray direction, weight
+  uint32_t *pix, *item, *smp;                 //            pixel, work item, sample number
+  float *lu, *lv;                             //            thin lens: the aperture point in the lens plane (null otherwise)
+};
+constexpr size_t kSpareLensBytes = 2 * kBlock * sizeof(float);
+
+// main.rs:92-121, first half: which sample follows the one the lane has in flight (next of the chunk, or the first of a new
+// work item from the wave's pool), its camera ray (camera.rs sample()).  Whole (converged) wave; `want` = the lane lacks a spare.
 template <class LS>
-LR_DEV void path_finish(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, WavePool& pool,
-                        uint32_t& pend, bool& pending, bool& dry, LdsRow* s_acc, uint32_t* s_end, uint32_t& n_done) {
-  const uint32_t tid = threadIdx.x;
-  bool need_item = c.fresh;
+LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevParams& rp, const LS& ls, const PathCtl& c, WavePool& pool,
+                             const SpareLds& sp, bool want) {
+  const uint32_t tid = fresh_v(threadIdx.x);
+  uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w) + 1u;
   uint32_t item = 0, end = 0;
-  uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w);
-  V3 sum = v3(0, 0, 0);
-  if (c.finished) {
-    float4 a = row4(s_acc[tid]);
-    item = __float_as_uint(a.w);
-    end = s_end[tid];
-    V3 delta = v3(ls.rad.v);
-    if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (delta * ls.ray_d.v.w) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
-    sum = v3(a) + delta;
-    sample += 1;
-    if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
-  }
-  n_done += (uint32_t)__builtin_popcountll(__ballot(c.finished));
+  if (want && !c.fresh) { item = __float_as_uint(sp.acc[tid].w); end = sp.end[tid]; }
+  const bool need_item = want && (c.fresh || sample >= end);
   const uint64_t nm = __ballot(need_item);
   bool retired = false;
   if (nm != 0) {
     const uint32_t cnt = (uint32_t)__builtin_popcountll(nm);
-    if (pending && cnt > pool.a0 + pool.a1) {                       // the refill issued an iteration ago
-      uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
-      pending = false;
-      if (nb < st.n_items) { pool.r1 = nb; pool.a1 = st.n_items - nb < st.pool_batch ? st.n_items - nb : st.pool_batch; }
-      else dry = true;
-      if (pool.a0 == 0) { pool.r0 = pool.r1; pool.a0 = pool.a1; pool.a1 = 0; }
+    uint32_t r1 = 0, a1 = 0;
+    if (cnt > pool.a0 && !pool.dry) {                               // one trip to the dispenser per pool_batch items: the wave waits for it
+      const uint32_t ask = st.pool_batch > cnt - pool.a0 ? st.pool_batch : cnt - pool.a0;
+      uint32_t nb = 0;
+      if (lane_id() == 0) nb = atomicAdd(st.next_item, ask);
+      r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+      const uint32_t n_items = st.n_items;
+      if (r1 < n_items) a1 = n_items - r1 < ask ? n_items - r1 : ask;
+      if (a1 < ask) pool.dry = true;
     }
     const uint32_t k = rank_in_mask(nm);
-    const bool short_of = need_item && !(k < pool.a0 + pool.a1);
-    uint32_t direct = 0xffffffffu;
-    if (!dry && !pending) direct = wave_reserve(st.next_item, short_of);   // pool empty and nothing in flight (start of the render, tiny jobs)
     if (need_item) {
       if (k < pool.a0) item = pool.r0 + k;
-      else if (k - pool.a0 < pool.a1) item = pool.r1 + (k - pool.a0);
-      else if (direct < st.n_items) item = direct;
+      else if (k - pool.a0 < a1) item = r1 + (k - pool.a0);
       else retired = true;
       if (!retired) {
-        uint32_t chunk = item / st.n_pix, rank = item - chunk * st.n_pix;
+        const uint32_t n_pix = fresh_s(st.n_pix);
+        uint32_t chunk = item / n_pix, rank = item - chunk * n_pix;
         pixel = st.rank_pixel[rank];
         sample = chunk * st.chunk_spp;
-        end = sample + st.chunk_spp;
-        if (end > (uint32_t)rp.spp) end = (uint32_t)rp.spp;
-        sum = v3(0, 0, 0);
       }
     }
     // advance the pool by what was handed out (wave-uniform)
-    uint32_t t0 = cnt < pool.a0 ? cnt : pool.a0;
-    pool.r0 += t0; pool.a0 -= t0;
-    uint32_t rest = cnt - t0, t1 = rest < pool.a1 ? rest : pool.a1;
-    pool.r1 += t1; pool.a1 -= t1;
-    if (pool.a0 == 0) { pool.r0 = pool.r1; pool.a0 = pool.a1; pool.a1 = 0; }
-    if (__ballot(short_of && !(direct < st.n_items)) != 0 && !pending) dry = true;
+    if (cnt < pool.a0) { pool.r0 += cnt; pool.a0 -= cnt; }
+    else { const uint32_t u = cnt - pool.a0 < a1 ? cnt - pool.a0 : a1; pool.r0 = r1 + u; pool.a0 = a1 - u; }
   }
-  if (c.finished || c.fresh) {
+  if (want) {
     if (retired) {
-      ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+      sp.item[tid] = kNoItem;
     } else {
-      s_acc[tid] = (RowVec){sum.x, sum.y, sum.z, __uint_as_float(item)};
-      s_end[tid] = end;
       Draw4 d0 = rng_block(rp.seed, pixel, sample, 0u);
-      uint32_t y = pixel / (uint32_t)sc.cam.res_w, x = pixel - y * (uint32_t)sc.cam.res_w;
-      V3 o, d; float g;
-      camera_sample(sc.cam, (int)x, (int)y, d0, &o, &d, &g);
-      ls.ray_o.v = make_float4(o.x, o.y, o.z, __int_as_float(0));
-      ls.ray_d.v = make_float4(d.x, d.y, d.z, g);
-      ls.thr.v = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
-      ls.rad.v = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
+      const uint32_t res_w = (uint32_t)fresh_s(sc.cam.res_w);
+      uint32_t y = pixel / res_w, x = pixel - y * res_w;
+      V3 o, d; float g, lens[2] = {0.0f, 0.0f};
+      camera_sample(sc.cam, (int)x, (int)y, d0, &o, &d, &g, lens);
+      sp.dir[tid] = (RowVec){d.x, d.y, d.z, g};
+      sp.pix[tid] = pixel; sp.item[tid] = item; sp.smp[tid] = sample;
+      if (sp.lu) { sp.lu[tid] = lens[0]; sp.lv[tid] = lens[1]; }
     }
   }
-  c.finished = false; c.fresh = false;
+}
+
+// main.rs:92-121, second half, for the lanes in `fin` (their sample ended, or they have no item yet; each has a spare): fold the
+// radiance into the chunk sum, write the sum out if the spare belongs to another work item, install the spare.  Returns
+// whether the lane retired.
+template <class LS>
+LR_DEV bool path_consume(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, const SpareLds& sp, bool fin, uint32_t* s_stat) {
+  const uint32_t tid = fresh_v(threadIdx.x);
+  stat_count(&s_stat[ST_SAMPLES], __ballot(fin && c.finished));
+  bool retired = false;
+  if (fin) {
+    const uint32_t item2 = sp.item[tid];
+    V3 sum = v3(0, 0, 0);
+    bool other = true;
+    if (c.finished) {
+      float4 a = row4(sp.acc[tid]);
+      V3 delta = v3(ls.rad.v);
+      if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (delta * ls.ray_d.v.w) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
+      sum = v3(a) + delta;
+      other = item2 != __float_as_uint(a.w);
+      if (other) { st.partial[__float_as_uint(a.w)] = make_float4(sum.x, sum.y, sum.z, 0.0f); sum = v3(0, 0, 0); }
+    }
+    if (item2 == kNoItem) {
+      retired = true;
+      ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+    } else {
+      const float4 dg = row4(sp.dir[tid]);
+      const uint32_t sample = sp.smp[tid];
+      sp.acc[tid] = (RowVec){sum.x, sum.y, sum.z, __uint_as_float(item2)};
+      if (other) { uint32_t end = sample + st.chunk_spp; sp.end[tid] = end > (uint32_t)rp.spp ? (uint32_t)rp.spp : end; }
+      V3 o = camera_origin(sc.cam, sp.lu ? sp.lu[tid] : 0.0f, sp.lv ? sp.lv[tid] : 0.0f);
+      ls.ray_o.v = make_float4(o.x, o.y, o.z, __int_as_float(0));
+      ls.ray_d.v = dg;
+      ls.thr.v = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sp.pix[tid]));
+      ls.rad.v = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
+    }
+    c.finished = false; c.fresh = false;
+  }
+  return retired;
+}
+
+// The finish stage of both fused kernels (converged wave): consume, produce spares where the wave is short of them, and
+// consume again for the lanes that had none.  `spare` = the lane has one (retired lanes: true, they never want another).
+template <class LS>
+LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, WavePool& pool,
+                               const SpareLds& sp, bool& spare, uint32_t* s_stat, PathDiag* dg = nullptr) {
+  (void)dg;
+  const bool fin1 = (c.finished || c.fresh) && spare;
+  if (__ballot(fin1) != 0) {
+    const bool r = path_consume(sc, st, rp, ls, c, sp, fin1, s_stat);
+    if (fin1) spare = r;
+  }
+  const bool unserved = c.finished || c.fresh;
+  const uint64_t um = __ballot(unserved);
+  if (um != 0 || (int)__builtin_popcountll(__ballot(!spare)) >= LR_SPARE_BATCH) {
+    LR_DIAG_ONLY(unsigned long long tb = __builtin_amdgcn_s_memtime(); if (dg) { dg->n_batch += 1; dg->l_batch += (unsigned)__builtin_popcountll(__ballot(!spare)); dg->n_forced += um != 0; })
+    path_spare_batch(sc, st, rp, ls, c, pool, sp, !spare);
+    LR_DIAG_ONLY(if (dg) dg->cyc_batch += __builtin_amdgcn_s_memtime() - tb;)
+    spare = true;
+    if (um != 0) {
+      const bool r = path_consume(sc, st, rp, ls, c, sp, unserved, s_stat);
+      if (unserved) spare = r;
+    }
+  }
 }
 
 // One vertex for the lanes whose ray is done: hit -> scene.rs:153-193, miss -> sky.  `rec(prim, row)` reads the 64-B shading
 // record.  Leaves the next ray (and possibly a connection to test) in ls, or c.finished with the final radiance in ls.rad.
 template <uint32_t MTS, int NEE = -1, class LS, class RecFn>
-LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl& c, bool live, float t, int prim, RecFn rec, uint32_t& n_sky) {
+LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl& c, bool live, float t, int prim, RecFn rec, uint32_t* s_stat) {
   const bool hitv = live && prim >= 0, miss = live && prim < 0;
   if (hitv) {
     VertexIn in;
@@ -267,7 +335,7 @@ LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl
       ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
       c.finished = true;
     }
-    if (sc.sky_type == LR_SKY_IBL) n_sky += (uint32_t)__builtin_popcountll(__ballot(miss));
+    if (sc.sky_type == LR_SKY_IBL) stat_count(&s_stat[ST_SKY], __ballot(miss));
   }
 }
 
@@ -279,10 +347,13 @@ template <uint32_t MTS>
 __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc, DevState st, DevParams rp, const float4* __restrict__ flat_prims) {
   __shared__ RowVec s_rec[kFlatMax * kRecStride];
   __shared__ RowVec s_emit[kFlatMax * 3];
-  __shared__ RowVec s_acc[kBlock];
-  __shared__ uint32_t s_end[kBlock];
+  __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
+  __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
+  __shared__ float s_lens[2 * kBlock];
   __shared__ uint32_t s_stat[ST_COUNT];
   const uint32_t tid = threadIdx.x;
+  const bool lens = sc.cam.type == LR_CAMERA_THIN_LENS;
+  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, lens ? s_lens : nullptr, lens ? s_lens + kBlock : nullptr};
   if (tid < ST_COUNT) s_stat[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 4u; i += kBlock) {
     float4 v = sc.shade[i];
@@ -300,25 +371,17 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
-  WavePool pool = {0, 0, 0, 0};
-  uint32_t pend = 0; bool pending = false, dry = false;
-  uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;                // wave-uniform: only touched where the wave is converged
+  WavePool pool = {0, 0, false};
+  bool spare = false;
   while (true) {
-    // ---- refill the wave's pool one iteration ahead of need ----
-    if (!pending && !dry && pool.a1 == 0 && pool.a0 < st.pool_low) {
-      pend = 0;
-      if (lane_id() == 0) pend = atomicAdd(st.next_item, st.pool_batch);
-      pending = true;
-    }
-    // ---- finish: fold, next item, next camera sample ----
-    if (__ballot(c.finished || c.fresh) != 0)
-      path_finish(sc, st, rp, ls, c, pool, pend, pending, dry, (LdsRow*)s_acc, s_end, n_done);
+    // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
+    path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat);
     const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
     const uint64_t lm = __ballot(live);
     if (lm == 0) break;
-    n_seg += (uint32_t)__builtin_popcountll(lm);
+    stat_count(&s_stat[ST_SEGMENTS], lm);
     const uint64_t sm = __ballot(live && c.has_sh);
-    n_shq += (uint32_t)__builtin_popcountll(sm);
+    stat_count(&s_stat[ST_SHADOW], sm);
     // ---- trace: closest hit + the pending connection, one pass over the primitive rows ----
     float t = 3.0e38f; int prim = -1;
     if (live) {
@@ -338,11 +401,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       }
     }
     // ---- vertex: shade the hit or fold the sky ----
-    path_vertex<MTS>(sc, rp, ls, c, live, t, prim, rec, n_sky);
-  }
-  if (lane_id() == 0) {
-    atomicAdd(&s_stat[ST_SEGMENTS], n_seg); atomicAdd(&s_stat[ST_SHADOW], n_shq);
-    atomicAdd(&s_stat[ST_SAMPLES], n_done); atomicAdd(&s_stat[ST_SKY], n_sky);
+    path_vertex<MTS>(sc, rp, ls, c, live, t, prim, rec, s_stat);
   }
   __syncthreads();
   stat_flush(st.stats, s_stat);
@@ -471,14 +530,20 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
   return ptrav_pop(sc, s, stk_n);
 }
 template <bool CONN>
-LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go) {
+LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
+  (void)dg;
 #pragma unroll 1
   for (int it = 0; it < kDescendBurst; ++it) {
     bool nm = go && s.cur >= 0;
-    if (__ballot(nm) == 0) break;
+    const uint64_t bm = __ballot(nm);
+    if (bm == 0) break;
+    LR_DIAG_ONLY(unsigned long long t0 = __builtin_amdgcn_s_memtime();)
     if (nm) go = ptrav_node<CONN>(sc, s, o, stk_n);
+    LR_DIAG_ONLY(dg->node_steps += 1; dg->node_lanes += (unsigned)__builtin_popcountll(bm); dg->cyc_node += __builtin_amdgcn_s_memtime() - t0;)
   }
+  LR_DIAG_ONLY(const uint64_t lm = __ballot(go && s.cur < 0); unsigned long long t1 = __builtin_amdgcn_s_memtime();)
   if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, o, stk_n);
+  LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
 #ifndef LR_PATHT_WAVES
@@ -495,12 +560,14 @@ inline int path_tree_waves(bool nee) { return nee ? LR_PATHT_WAVES : LR_PATHT_WA
 // NEE: the integrator is pt-direct (connections are produced, walked and resolved) or pt (none of that code exists)
 template <uint32_t MTS, bool NEE>
 __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(DevScene sc, DevState st, DevParams rp) {
-  extern __shared__ uint32_t lds[];                                  // traversal stack: sc.stack_lds entries per lane
-  __shared__ RowVec s_acc[kBlock];
-  __shared__ uint32_t s_end[kBlock];
+  extern __shared__ uint32_t lds[];                                  // traversal stack: sc.stack_lds entries per lane; thin lens: + kSpareLensBytes
+  __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
+  __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ uint32_t s_stat[ST_COUNT];
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
+  float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
+  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, s_lens, s_lens ? s_lens + kBlock : nullptr};
   if (tid < ST_COUNT) s_stat[tid] = 0;
   __syncthreads();
   auto rec = [&](int prim, int row) -> float4 { return sc.shade[4 * (size_t)prim + row]; };
@@ -512,20 +579,16 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
   PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f), 0.0f, false);
   bool has = false, fin = false;                                     // the lane has a ray in flight / its walk is over
-  WavePool pool = {0, 0, 0, 0};
-  uint32_t pend = 0; bool pending = false, dry = false;
-  uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0;                // wave-uniform: only touched where the wave is converged
+  WavePool pool = {0, 0, false};
+  bool spare = false;
+  LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
-    if (!pending && !dry && pool.a1 == 0 && pool.a0 < st.pool_low) {
-      pend = 0;
-      if (lane_id() == 0) pend = atomicAdd(st.next_item, st.pool_batch);
-      pending = true;
-    }
     // ================= retire point (converged) =================
     // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
     if constexpr (NEE) {
       const bool fs = has && fin && tr.shadow;
       if (__ballot(fs) != 0) {
+        LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(fs));)
         if (fs) {
           V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), tr.d, v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
           ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
@@ -533,24 +596,34 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
           ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
           fin = false;
         }
+        LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq;)
       }
     }
     // (b) continuation rays whose walk is over: the vertex
     {
       const bool fm = has && fin;                                      // (a) left only closest-hit walks with fin set
       if (__ballot(fm) != 0) {
-        path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, n_sky);
+        LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
+        path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, s_stat);
         if (fm) { has = false; fin = false; }
+        LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
       }
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
-    if (__ballot(c.finished || c.fresh) != 0)
-      path_finish(sc, st, rp, ls, c, pool, pend, pending, dry, (LdsRow*)s_acc, s_end, n_done);
+    {
+      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));)
+#ifdef LR_DIAG
+      path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat, &dg);
+#else
+      path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat);
+#endif
+      LR_DIAG_ONLY(dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;)
+    }
     // (d) every live lane without a ray starts its next one: the connection first, if its vertex left one
     {
       const bool start = !has && __float_as_int(ls.ray_o.v.w) >= 0;
-      n_seg += (uint32_t)__builtin_popcountll(__ballot(start));
-      if constexpr (NEE) n_shq += (uint32_t)__builtin_popcountll(__ballot(start && c.has_sh));
+      stat_count(&s_stat[ST_SEGMENTS], __ballot(start));
+      if constexpr (NEE) stat_count(&s_stat[ST_SHADOW], __ballot(start && c.has_sh));
       if (start) {
         if (NEE && c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v), ls.sh_d.v.w, true);
         else ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
@@ -564,13 +637,23 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     const int thresh = live_n / 2 < kRefillBelow ? live_n / 2 : kRefillBelow;
     const V3 o = v3(ls.ray_o.v);
     bool go = has && !fin;
+#ifdef LR_DIAG
+    tq = __builtin_amdgcn_s_memtime(); dg.walks += 1; dg.walk_lanes += (unsigned)__builtin_popcountll(__ballot(go));
+    do { ptrav_burst<NEE>(sc, tr, o, stk_n, go, &dg); } while (__builtin_popcountll(__ballot(go)) > thresh);
+    dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq;
+#else
     do { ptrav_burst<NEE>(sc, tr, o, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+#endif
     fin = has && !go;
   }
+#ifdef LR_DIAG
+  dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
   if (lane_id() == 0) {
-    atomicAdd(&s_stat[ST_SEGMENTS], n_seg); atomicAdd(&s_stat[ST_SHADOW], n_shq);
-    atomicAdd(&s_stat[ST_SAMPLES], n_done); atomicAdd(&s_stat[ST_SKY], n_sky);
+    unsigned long long* od = st.stats + (size_t)kStatShards * kStatStride + 24;
+    const unsigned long long* v = (const unsigned long long*)&dg;
+    for (int i = 0; i < (int)(sizeof(PathDiag) / 8); ++i) atomicAdd(od + i, v[i]);
   }
+#endif
   __syncthreads();
   stat_flush(st.stats, s_stat);
 }

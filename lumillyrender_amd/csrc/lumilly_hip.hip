@@ -592,7 +592,33 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t stream_slots = (uint32_t)std::min<uint64_t>(32u << 20, std::max<uint64_t>(1u << 20, n_items64 / 8));
   uint32_t n_slots = rp_in.path_slots > 0 ? (uint32_t)rp_in.path_slots : (resident ? (uint32_t)(s.n_cus * resident_per_cu * RB) : stream_slots);
   if (resident) n_slots = std::min<uint32_t>(n_slots, (uint32_t)(s.n_cus * resident_per_cu * RB));   // every workgroup must be resident: no grid-stride
-  if (fused) n_slots = (uint32_t)(s.n_cus * (s.dev.n_flat > 0 ? LR_PATH_WAVES : path_tree_waves(rp_in.integrator == LR_INTEGRATOR_PT_DIRECT)) * kBlock);   // one path per lane of every resident wave
+  // fused: one path per lane of every resident wave.  The tree kernel keeps 10 stack entries per lane in LDS (16 in the streaming
+  // kernels; measured free down to 10) beside the spare camera samples, so that 7 (pt) / 6 (pt-direct, thin lens) workgroups fit a CU.
+  const void* fused_kernel = nullptr; size_t fused_lds = 0; int fused_stack = 0;
+  if (fused) {
+    uint32_t mt_mask = 0;
+    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+    const uint32_t only = mt_mask | 1u;                                // the kernels are instantiated for the BASELINE material sets and for "anything"
+    int want_waves;
+    if (s.dev.n_flat > 0) {
+      fused_kernel = mt_mask == 1u ? (const void*)k_path_flat<1u> : (only == 9u ? (const void*)k_path_flat<9u> : (const void*)k_path_flat<31u>);
+      want_waves = LR_PATH_WAVES;
+    } else {
+      const bool nee_k = rp_in.integrator == LR_INTEGRATOR_PT_DIRECT;  // (a pt-direct scene without emitters runs the NEE kernel: the branch is then never taken)
+      fused_kernel = only == 1u ? (nee_k ? (const void*)k_path_tree<1u, true> : (const void*)k_path_tree<1u, false>)
+                   : only == 9u ? (nee_k ? (const void*)k_path_tree<9u, true> : (const void*)k_path_tree<9u, false>)
+                                : (nee_k ? (const void*)k_path_tree<31u, true> : (const void*)k_path_tree<31u, false>);
+      want_waves = path_tree_waves(nee_k);
+      fused_stack = std::min(s.stack_depth, std::getenv("LR_STACK_LDS") ? stack_lds_limit() : kStackLdsFused);
+      fused_lds = (size_t)fused_stack * kBlock * 4 + (s.dev.cam.type == LR_CAMERA_THIN_LENS ? kSpareLensBytes : 0);
+      if (fused_lds > 48 * 1024) HIP_OK(hipFuncSetAttribute(fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+    }
+    int fit = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fused_kernel, kBlock, fused_lds));
+    if (fit < 1) fail(LR_EUNSUPPORTED, "the fused kernel does not fit a compute unit");
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lumilly_hip] fused kernel: %d workgroups per CU fit (%d wanted), %zu B of dynamic LDS\n", fit, want_waves, fused_lds);
+    n_slots = (uint32_t)(s.n_cus * std::min(fit, want_waves) * kBlock);
+  }
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
   const uint32_t n_seg = n_slots / kSeg;
@@ -613,7 +639,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const bool sort_rays = !resident && s.dev.n_flat == 0 && std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 1;
   if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
   s.counters.ensure(4);
-  s.stats_dev.ensure((size_t)kStatShards * kStatStride + 32);
+  s.stats_dev.ensure((size_t)kStatShards * kStatStride + 64);
   s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
@@ -655,7 +681,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   S.path_slots = n_slots; S.pipeline = fused ? 2 : (resident ? 1 : 0);
 
   HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
-  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 32) * sizeof(unsigned long long), st));
+  HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 64) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
   // streaming traversal kernels: at most kStackLdsMax stack entries per lane in LDS (6 workgroups of 25 KB per CU, the
@@ -674,33 +700,20 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   Launcher L{s, profile};
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
   if (n_items > 0 && fused) {
-    uint32_t mt_mask = 0;
-    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
     // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
     ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
     ds.pool_low = std::max<uint32_t>(1, ds.pool_batch / 2);
-    if (s.dev.n_flat == 0 && dsc.spill_depth > 0) {
-      s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
-      dsc.stack_spill = s.stack_spill.p;
-    }
-    const uint32_t only = mt_mask | 1u;                                // the kernels are instantiated for the BASELINE material sets and for "anything"
-    L.run(LR_K_PATH, [&] {
-      if (s.dev.n_flat > 0) {
-        if (mt_mask == 1u) hipLaunchKernelGGL(k_path_flat<1u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
-        else if (only == 9u) hipLaunchKernelGGL(k_path_flat<9u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
-        else hipLaunchKernelGGL(k_path_flat<31u>, dim3(blocks), dim3(kBlock), 0, st, dsc, ds, dp, (const float4*)s.flat.p);
-      } else {
-        const bool nee_k = dp.integrator == LR_INTEGRATOR_PT_DIRECT;     // (a pt-direct scene without emitters runs the NEE kernel: the branch is then never taken)
-        auto launch_tree = [&](auto kernel) {
-          if (lds > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), lds, st, dsc, ds, dp);
-        };
-        if (only == 1u) { if (nee_k) launch_tree(k_path_tree<1u, true>); else launch_tree(k_path_tree<1u, false>); }
-        else if (only == 9u) { if (nee_k) launch_tree(k_path_tree<9u, true>); else launch_tree(k_path_tree<9u, false>); }
-        else { if (nee_k) launch_tree(k_path_tree<31u, true>); else launch_tree(k_path_tree<31u, false>); }
+    if (s.dev.n_flat == 0) {
+      dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
+      if (dsc.spill_depth > 0) {
+        s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
+        dsc.stack_spill = s.stack_spill.p;
       }
-    });
+    }
+    const float4* flat_rows = (const float4*)s.flat.p;
+    void* args[4] = {&dsc, &ds, &dp, (void*)&flat_rows};                // k_path_tree takes the first three
+    L.run(LR_K_PATH, [&] { HIP_OK(hipLaunchKernel(fused_kernel, dim3(blocks), dim3(kBlock), args, fused_lds, st)); });
     S.iterations = 1;
     HIP_OK(hipStreamSynchronize(st));
   } else if (n_items > 0 && resident) {
@@ -875,6 +888,21 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         100.0 * d.cyc_retire / d.cyc_total, 100.0 * d.cyc_fetch / d.cyc_total,
         100.0 * (double)(d.cyc_total - d.cyc_node - d.cyc_leaf - d.cyc_retire - d.cyc_fetch) / d.cyc_total,
         (double)d.node_lanes / std::max<unsigned long long>(d.rays, 1), (double)d.leaf_lanes / std::max<unsigned long long>(d.rays, 1));
+  }
+#endif
+#ifdef LR_DIAG
+  {
+    PathDiag d;
+    HIP_OK(hipMemcpy(&d, s.stats_dev.p + (size_t)kStatShards * kStatStride + 24, sizeof(d), hipMemcpyDeviceToHost));
+    auto pc = [&](unsigned long long c) { return 100.0 * (double)c / (double)d.cyc_total; };
+    auto per = [](unsigned long long a, unsigned long long b) { return (double)a / (double)std::max<unsigned long long>(b, 1); };
+    if (d.walks) std::fprintf(stderr, "[LR_DIAG] k_path_tree wave cycles: resolve %.1f%% (%.1f lanes, %.0f cyc) vertex %.1f%% (%.1f lanes, %.0f cyc) finish %.1f%% (%.1f lanes, %.0f cyc) "
+        "walk %.1f%% [node %.1f%% (%.1f lanes, %.0f cyc/step) leaf %.1f%% (%.1f lanes, %.0f cyc/step)] other %.1f%%; per walk: %.1f lanes in, %.1f node steps, %.1f leaf steps; spare batches %.3f per retire point (%.1f lanes, %.0f cyc, %.1f%% of the cycles, forced %.1f%%)\n",
+        pc(d.cyc_resolve), per(d.l_resolve, d.n_resolve), per(d.cyc_resolve, d.n_resolve), pc(d.cyc_vertex), per(d.l_vertex, d.n_vertex), per(d.cyc_vertex, d.n_vertex),
+        pc(d.cyc_finish), per(d.l_finish, d.n_finish), per(d.cyc_finish, d.n_finish), pc(d.cyc_walk), pc(d.cyc_node), per(d.node_lanes, d.node_steps), per(d.cyc_node, d.node_steps),
+        pc(d.cyc_leaf), per(d.leaf_lanes, d.leaf_steps), per(d.cyc_leaf, d.leaf_steps),
+        pc(d.cyc_total - d.cyc_resolve - d.cyc_vertex - d.cyc_finish - d.cyc_walk), per(d.walk_lanes, d.walks), per(d.node_steps, d.walks), per(d.leaf_steps, d.walks),
+        per(d.n_batch, d.n_finish), per(d.l_batch, d.n_batch), per(d.cyc_batch, d.n_batch), pc(d.cyc_batch), 100.0 * per(d.n_forced, d.n_batch));
   }
 #endif
   unsigned long long hstats[ST_COUNT] = {0};
