@@ -34,15 +34,17 @@ namespace lr {
 // segment in LDS: one global atomic per wave on a shared word costs ~12 ns and serialises (the first
 // version of these kernels spent >90 % of its time there), an LDS atomic does not.
 // ------------------------------------------------------------------------------------------
-// (every kernel here is launched with one-dimensional workgroups of whole waves: the lane id is a mask of a live register, not
-//  a loop-invariant mbcnt result that the allocator parks in scratch)
-LR_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 // A loop-invariant value, made opaque at the point of use: whatever is computed from it (an integer reciprocal, a float
 // conversion, an LDS address) is computed THERE instead of once at kernel entry.  In the persistent kernels everything hoisted
 // to the entry lives across the whole loop, and what does not fit the registers is reloaded from scratch -- a round trip
 // through the vector-memory path (3000+ cycles under a tree walk's load) where ten instructions would have done.
 template <class T> LR_DEV T fresh_s(T v) { asm volatile("" : "+s"(v)); return v; }     // wave-uniform value
 LR_DEV uint32_t fresh_v(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// the lane id: two instructions wherever it is needed (the mask is opaque, so it is not an entry-block value either)
+LR_DEV uint32_t lane_id() { const uint32_t m = fresh_s(~0u); return __builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u)); }
+// threadIdx.x from the wave's first thread id (a scalar, kept by the caller) -- threadIdx.x itself is an entry value too
+LR_DEV uint32_t tid_of(uint32_t wave_base) { return wave_base + lane_id(); }
+LR_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // count `mask`'s lanes into a workgroup statistic (converged wave): one LDS atomic without return, no register kept
 LR_DEV void stat_count(uint32_t* lds_stat, uint64_t mask) {
   if (mask != 0 && lane_id() == 0) atomicAdd(lds_stat, (uint32_t)__builtin_popcountll(mask));

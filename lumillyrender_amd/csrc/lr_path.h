@@ -45,7 +45,9 @@ struct PathDiag { unsigned long long cyc_total, cyc_resolve, n_resolve, l_resolv
                   cyc_walk, walks, walk_lanes, node_steps, node_lanes, cyc_node, leaf_steps, leaf_lanes, cyc_leaf, leaf_prims, n_batch, l_batch, n_forced, cyc_batch; };
 
 // ---- wave-level work-item pool: a range of reserved item ids in scalar registers ----
-struct WavePool { uint32_t r0, a0; bool dry; };   // next reserved item, how many are left, the dispenser has run out
+// Four LDS words per wave {next reserved item, how many are left, the dispenser has run out, -}: only the spare batch touches
+// them, and as registers they would live across the whole walk (the allocator had them in scratch).
+constexpr int kPoolWords = 4;
 
 // ---- the pair test: closest hit of (o, d) and in-window visibility of (o, sd, sdist) against one primitive ----
 // Wave-level skips of the v and t stages of the pair test when no lane of the wave needs them (they never change a result):
@@ -186,15 +188,17 @@ struct SpareLds {
   LdsRow* dir;                                // the spare: camera ray direction, weight
   uint32_t *pix, *item, *smp;                 //            pixel, work item, sample number
   float *lu, *lv;                             //            thin lens: the aperture point in the lens plane (null otherwise)
+  uint32_t wave_base;                         // threadIdx.x of the wave's lane 0
+  uint32_t* pool;                             // this wave's kPoolWords
 };
 constexpr size_t kSpareLensBytes = 2 * kBlock * sizeof(float);
 
 // main.rs:92-121, first half: which sample follows the one the lane has in flight (next of the chunk, or the first of a new
 // work item from the wave's pool), its camera ray (camera.rs sample()).  Whole (converged) wave; `want` = the lane lacks a spare.
 template <class LS>
-LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevParams& rp, const LS& ls, const PathCtl& c, WavePool& pool,
+LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevParams& rp, const LS& ls, const PathCtl& c,
                              const SpareLds& sp, bool want) {
-  const uint32_t tid = fresh_v(threadIdx.x);
+  const uint32_t tid = tid_of(sp.wave_base);
   uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w) + 1u;
   uint32_t item = 0, end = 0;
   if (want && !c.fresh) { item = __float_as_uint(sp.acc[tid].w); end = sp.end[tid]; }
@@ -203,20 +207,21 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
   bool retired = false;
   if (nm != 0) {
     const uint32_t cnt = (uint32_t)__builtin_popcountll(nm);
+    uint32_t r0 = uniform(sp.pool[0]), a0 = uniform(sp.pool[1]), dry = uniform(sp.pool[2]);
     uint32_t r1 = 0, a1 = 0;
-    if (cnt > pool.a0 && !pool.dry) {                               // one trip to the dispenser per pool_batch items: the wave waits for it
-      const uint32_t ask = st.pool_batch > cnt - pool.a0 ? st.pool_batch : cnt - pool.a0;
+    if (cnt > a0 && !dry) {                                         // one trip to the dispenser per pool_batch items: the wave waits for it
+      const uint32_t ask = st.pool_batch > cnt - a0 ? st.pool_batch : cnt - a0;
       uint32_t nb = 0;
       if (lane_id() == 0) nb = atomicAdd(st.next_item, ask);
-      r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+      r1 = uniform(nb);
       const uint32_t n_items = st.n_items;
       if (r1 < n_items) a1 = n_items - r1 < ask ? n_items - r1 : ask;
-      if (a1 < ask) pool.dry = true;
+      if (a1 < ask) dry = 1u;
     }
     const uint32_t k = rank_in_mask(nm);
     if (need_item) {
-      if (k < pool.a0) item = pool.r0 + k;
-      else if (k - pool.a0 < a1) item = r1 + (k - pool.a0);
+      if (k < a0) item = r0 + k;
+      else if (k - a0 < a1) item = r1 + (k - a0);
       else retired = true;
       if (!retired) {
         const uint32_t n_pix = fresh_s(st.n_pix);
@@ -226,8 +231,9 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
       }
     }
     // advance the pool by what was handed out (wave-uniform)
-    if (cnt < pool.a0) { pool.r0 += cnt; pool.a0 -= cnt; }
-    else { const uint32_t u = cnt - pool.a0 < a1 ? cnt - pool.a0 : a1; pool.r0 = r1 + u; pool.a0 = a1 - u; }
+    if (cnt < a0) { r0 += cnt; a0 -= cnt; }
+    else { const uint32_t u = cnt - a0 < a1 ? cnt - a0 : a1; r0 = r1 + u; a0 = a1 - u; }
+    if (lane_id() == 0) { sp.pool[0] = r0; sp.pool[1] = a0; sp.pool[2] = dry; }
   }
   if (want) {
     if (retired) {
@@ -250,7 +256,7 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
 // whether the lane retired.
 template <class LS>
 LR_DEV bool path_consume(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, const SpareLds& sp, bool fin, uint32_t* s_stat) {
-  const uint32_t tid = fresh_v(threadIdx.x);
+  const uint32_t tid = tid_of(sp.wave_base);
   stat_count(&s_stat[ST_SAMPLES], __ballot(fin && c.finished));
   bool retired = false;
   if (fin) {
@@ -287,7 +293,7 @@ LR_DEV bool path_consume(const DevScene& sc, const DevState& st, const DevParams
 // The finish stage of both fused kernels (converged wave): consume, produce spares where the wave is short of them, and
 // consume again for the lanes that had none.  `spare` = the lane has one (retired lanes: true, they never want another).
 template <class LS>
-LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, WavePool& pool,
+LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c,
                                const SpareLds& sp, bool& spare, uint32_t* s_stat, PathDiag* dg = nullptr) {
   (void)dg;
   const bool fin1 = (c.finished || c.fresh) && spare;
@@ -299,7 +305,7 @@ LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const Dev
   const uint64_t um = __ballot(unserved);
   if (um != 0 || (int)__builtin_popcountll(__ballot(!spare)) >= LR_SPARE_BATCH) {
     LR_DIAG_ONLY(unsigned long long tb = __builtin_amdgcn_s_memtime(); if (dg) { dg->n_batch += 1; dg->l_batch += (unsigned)__builtin_popcountll(__ballot(!spare)); dg->n_forced += um != 0; })
-    path_spare_batch(sc, st, rp, ls, c, pool, sp, !spare);
+    path_spare_batch(sc, st, rp, ls, c, sp, !spare);
     LR_DIAG_ONLY(if (dg) dg->cyc_batch += __builtin_amdgcn_s_memtime() - tb;)
     spare = true;
     if (um != 0) {
@@ -350,11 +356,13 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ float s_lens[2 * kBlock];
-  __shared__ uint32_t s_stat[ST_COUNT];
+  __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   const uint32_t tid = threadIdx.x;
   const bool lens = sc.cam.type == LR_CAMERA_THIN_LENS;
-  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, lens ? s_lens : nullptr, lens ? s_lens + kBlock : nullptr};
+  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, lens ? s_lens : nullptr, lens ? s_lens + kBlock : nullptr,
+                       uniform(threadIdx.x), s_pool + kPoolWords * (uniform(threadIdx.x) >> 6)};
   if (tid < ST_COUNT) s_stat[tid] = 0;
+  if (tid < kPoolWords * kBlock / 64) s_pool[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 4u; i += kBlock) {
     float4 v = sc.shade[i];
     s_rec[(i >> 2) * kRecStride + (i & 3u)] = (RowVec){v.x, v.y, v.z, v.w};
@@ -371,11 +379,10 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
-  WavePool pool = {0, 0, false};
   bool spare = false;
   while (true) {
     // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
-    path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat);
+    path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat);
     const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
     const uint64_t lm = __ballot(live);
     if (lm == 0) break;
@@ -563,12 +570,14 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   extern __shared__ uint32_t lds[];                                  // traversal stack: sc.stack_lds entries per lane; thin lens: + kSpareLensBytes
   __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
-  __shared__ uint32_t s_stat[ST_COUNT];
+  __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
-  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, s_lens, s_lens ? s_lens + kBlock : nullptr};
+  const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, s_lens, s_lens ? s_lens + kBlock : nullptr, uniform(threadIdx.x),
+                       s_pool + kPoolWords * (uniform(threadIdx.x) >> 6)};
   if (tid < ST_COUNT) s_stat[tid] = 0;
+  if (tid < kPoolWords * kBlock / 64) s_pool[tid] = 0;
   __syncthreads();
   auto rec = [&](int prim, int row) -> float4 { return sc.shade[4 * (size_t)prim + row]; };
 
@@ -579,7 +588,6 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
   PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f), 0.0f, false);
   bool has = false, fin = false;                                     // the lane has a ray in flight / its walk is over
-  WavePool pool = {0, 0, false};
   bool spare = false;
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
@@ -613,9 +621,9 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     {
       LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));)
 #ifdef LR_DIAG
-      path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat, &dg);
+      path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat, &dg);
 #else
-      path_finish_spares(sc, st, rp, ls, c, pool, sp, spare, s_stat);
+      path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat);
 #endif
       LR_DIAG_ONLY(dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;)
     }
