@@ -380,9 +380,16 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
   bool spare = false;
+  LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
     // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
+#ifdef LR_DIAG
+    tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));
+    path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat, &dg);
+    dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;
+#else
     path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat);
+#endif
     const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
     const uint64_t lm = __ballot(live);
     if (lm == 0) break;
@@ -391,6 +398,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
     stat_count(&s_stat[ST_SHADOW], sm);
     // ---- trace: closest hit + the pending connection, one pass over the primitive rows ----
     float t = 3.0e38f; int prim = -1;
+    LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.walks += 1; dg.walk_lanes += (unsigned)__builtin_popcountll(lm); dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(sm);)
     if (live) {
       const V3 o = v3(ls.ray_o.v), d = v3(ls.ray_d.v);
       if (sm != 0) {
@@ -408,8 +416,18 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       }
     }
     // ---- vertex: shade the hit or fold the sky ----
+    LR_DIAG_ONLY(dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(live && prim >= 0));)
     path_vertex<MTS>(sc, rp, ls, c, live, t, prim, rec, s_stat);
+    LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
   }
+#ifdef LR_DIAG
+  dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
+  if (lane_id() == 0) {
+    unsigned long long* od = st.stats + (size_t)kStatShards * kStatStride + 24;
+    const unsigned long long* v = (const unsigned long long*)&dg;
+    for (int i = 0; i < (int)(sizeof(PathDiag) / 8); ++i) atomicAdd(od + i, v[i]);
+  }
+#endif
   __syncthreads();
   stat_flush(st.stats, s_stat);
 }
@@ -536,11 +554,19 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
   }
   return ptrav_pop(sc, s, stk_n);
 }
+// node steps in a row before the lanes that reached a leaf get their turn: 2 in the pt kernel (7 waves per SIMD; 100k-triangle
+// scene 3865 vs 3794 Msamples/s with 3, 3444 with 4), 3 in the pt-direct one (thin-lens / IBL scene 3416 vs 3337 with 2)
+#ifndef LR_BURST_PT
+#define LR_BURST_PT 2
+#endif
+#ifndef LR_BURST_NEE
+#define LR_BURST_NEE 3
+#endif
 template <bool CONN>
 LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
   (void)dg;
 #pragma unroll 1
-  for (int it = 0; it < kDescendBurst; ++it) {
+  for (int it = 0; it < (CONN ? LR_BURST_NEE : LR_BURST_PT); ++it) {
     bool nm = go && s.cur >= 0;
     const uint64_t bm = __ballot(nm);
     if (bm == 0) break;
@@ -553,6 +579,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, boo
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
+#ifndef LR_RETIRE_EIGHTHS
+#define LR_RETIRE_EIGHTHS 4            // the walk stops for a retire point when this many eighths of the wave's rays are still under way
+#endif
 #ifndef LR_PATHT_WAVES
 #define LR_PATHT_WAVES 6
 #endif
@@ -642,7 +671,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     if (hm == 0) break;
     // ================= walk until at most half of the wave's rays are still under way =================
     const int live_n = __builtin_popcountll(hm);
-    const int thresh = live_n / 2 < kRefillBelow ? live_n / 2 : kRefillBelow;
+    const int thresh = live_n * LR_RETIRE_EIGHTHS / 8;
     const V3 o = v3(ls.ray_o.v);
     bool go = has && !fin;
 #ifdef LR_DIAG

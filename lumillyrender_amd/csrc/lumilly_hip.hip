@@ -896,7 +896,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     HIP_OK(hipMemcpy(&d, s.stats_dev.p + (size_t)kStatShards * kStatStride + 24, sizeof(d), hipMemcpyDeviceToHost));
     auto pc = [&](unsigned long long c) { return 100.0 * (double)c / (double)d.cyc_total; };
     auto per = [](unsigned long long a, unsigned long long b) { return (double)a / (double)std::max<unsigned long long>(b, 1); };
-    if (d.walks) std::fprintf(stderr, "[LR_DIAG] k_path_tree wave cycles: resolve %.1f%% (%.1f lanes, %.0f cyc) vertex %.1f%% (%.1f lanes, %.0f cyc) finish %.1f%% (%.1f lanes, %.0f cyc) "
+    if (d.walks && !d.node_steps) std::fprintf(stderr, "[LR_DIAG] k_path_flat wave cycles: finish %.1f%% (%.1f lanes ending, %.0f cyc) trace %.1f%% (%.1f lanes live, %.1f with a connection, %.0f cyc) "
+        "vertex %.1f%% (%.1f lanes at a hit, %.0f cyc); spare batches %.3f per iteration (%.1f lanes, %.0f cyc, %.1f%% of the cycles, forced %.1f%%)\n",
+        pc(d.cyc_finish), per(d.l_finish, d.n_finish), per(d.cyc_finish, d.n_finish), pc(d.cyc_walk), per(d.walk_lanes, d.walks), per(d.l_resolve, d.n_resolve), per(d.cyc_walk, d.walks),
+        pc(d.cyc_vertex), per(d.l_vertex, d.n_vertex), per(d.cyc_vertex, d.n_vertex),
+        per(d.n_batch, d.n_finish), per(d.l_batch, d.n_batch), per(d.cyc_batch, d.n_batch), pc(d.cyc_batch), 100.0 * per(d.n_forced, d.n_batch));
+    if (d.walks && d.node_steps) std::fprintf(stderr, "[LR_DIAG] k_path_tree wave cycles: resolve %.1f%% (%.1f lanes, %.0f cyc) vertex %.1f%% (%.1f lanes, %.0f cyc) finish %.1f%% (%.1f lanes, %.0f cyc) "
         "walk %.1f%% [node %.1f%% (%.1f lanes, %.0f cyc/step) leaf %.1f%% (%.1f lanes, %.0f cyc/step)] other %.1f%%; per walk: %.1f lanes in, %.1f node steps, %.1f leaf steps; spare batches %.3f per retire point (%.1f lanes, %.0f cyc, %.1f%% of the cycles, forced %.1f%%)\n",
         pc(d.cyc_resolve), per(d.l_resolve, d.n_resolve), per(d.cyc_resolve, d.n_resolve), pc(d.cyc_vertex), per(d.l_vertex, d.n_vertex), per(d.cyc_vertex, d.n_vertex),
         pc(d.cyc_finish), per(d.l_finish, d.n_finish), per(d.cyc_finish, d.n_finish), pc(d.cyc_walk), pc(d.cyc_node), per(d.node_lanes, d.node_steps), per(d.cyc_node, d.node_steps),
