@@ -32,11 +32,13 @@ struct LaneRow { float4 v; LR_DEV float4& operator[](uint32_t) { return v; } };
 template <bool LDS_TABLES>
 struct LaneStateT {
   LaneRow ray_o, ray_d, thr, rad, sh_d, sh_w;
-  const LdsRow* emit;                  // LDS_TABLES: the emitter rows, staged by the kernel
+  const LdsRow* emit;                  // the emitter rows, staged in LDS by the kernel (LDS_TABLES: always; otherwise null = read the scene blob)
 };
+constexpr int kEmitLds = 8;            // k_path_tree stages up to this many emitters (the scalar-load case of emitter_index)
 template <bool LDS_TABLES>
 LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int i) {
   if constexpr (LDS_TABLES) return row4(st.emit[i]);
+  else if (st.emit) return row4(st.emit[i]);      // (wave-uniform)
   else return sc.emit[i];
 }
 
@@ -600,6 +602,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
+  __shared__ RowVec s_emit[NEE ? kEmitLds * 3 : 1];
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
@@ -607,11 +610,15 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
                        s_pool + kPoolWords * (uniform(threadIdx.x) >> 6)};
   if (tid < ST_COUNT) s_stat[tid] = 0;
   if (tid < kPoolWords * kBlock / 64) s_pool[tid] = 0;
+  // a few emitters (area lights): their rows in LDS -- from the scene blob the vertex waited for them twice (the rows both
+  // primitive classes read, then the triangle's other two), two round trips of the four a pt-direct vertex made
+  const bool emit_lds = NEE && sc.n_emitters <= kEmitLds;
+  if (emit_lds && tid < (uint32_t)sc.n_emitters * 3u) { float4 v = sc.emit[tid]; s_emit[tid] = (RowVec){v.x, v.y, v.z, v.w}; }
   __syncthreads();
   auto rec = [&](int prim, int row) -> float4 { return sc.shade[4 * (size_t)prim + row]; };
 
   LaneStateT<false> ls;
-  ls.emit = nullptr;
+  ls.emit = emit_lds ? (const LdsRow*)s_emit : nullptr;
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
