@@ -6,7 +6,9 @@
 // direct-light connection) never leaves the lane's registers, waves never wait for each other, and the stages are plain
 // code in the lane's loop:
 //
-//   finish     main.rs:92-121: fold the finished sample into the chunk sum, draw the next work item, next camera sample
+//   finish     main.rs:92-121 in two halves: a lane whose path ended folds its radiance into the chunk sum and installs the
+//              camera sample it holds ready in LDS (path_consume); next work item + RNG + camera.rs sample() for every lane
+//              that lacks such a spare run as a batch at 20+ of 64 lanes (path_spare_batch)
 //   trace      closest hit of the lane's ray AND, in the same pass over the primitives, the visibility test of the
 //              direct-light connection the previous vertex left behind: both rays leave the same point (scene.rs:94-97,
 //              112-117), so per triangle  tv = o - p0,  qv = tv x e1  and  e2 . qv  (17 of the 57 operations of
@@ -18,8 +20,10 @@
 // Same device functions, same RNG keys, same chunk order and the same order of additions into a sample's radiance as the
 // other pipelines => bit-identical films (tests/test_gpu_parity_r3.py).
 //
-// Work items come from a per-WAVE pool held in scalar registers; its refill is a global atomic issued one iteration ahead,
-// so nobody waits for the dispenser.
+// Work items come from a per-WAVE pool of four LDS words, topped up by one global atomic per 64 items.  Nothing that is only
+// needed at the finish stage is kept in a register across the walk (fresh_s / fresh_v, lr_kernels.h): in a persistent kernel
+// every entry-block value is live for the whole render, and what the allocator parks in scratch comes back through the
+// vector-memory path at 3000+ cycles a reload.
 #pragma once
 #include "lr_kernels.h"
 
