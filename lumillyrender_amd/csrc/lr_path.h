@@ -319,6 +319,7 @@ LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const Dev
       if (unserved) spare = r;
     }
   }
+  c.finished = false; c.fresh = false;                               // (every such lane was served: nothing of these crosses the walk)
 }
 
 // One vertex for the lanes whose ray is done: hit -> scene.rs:153-193, miss -> sky.  `rec(prim, row)` reads the 64-B shading
@@ -450,14 +451,19 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
 // The traversal differs from trav_node / trav_leaf (lr_kernels.h) in two ways only: the query kind is a per-lane flag
 // (lanes of one wave walk connections and continuation rays side by side), and the origin is the path's (ls.ray_o).
 // =====================================================================================================================
-struct PTrav {
-  V3 d; float ix, iy, iz;
-  float dist, t; int prim, cur, sp;
-  bool shadow, occluded;
+struct PTrav {                         // (the direction and, for a connection, the distance stay in the lane's rows: ray_d / sh_d)
+  float ix, iy, iz;
+  float t; int prim, cur, sp;
+  bool occluded;
 };
+// the ray a lane is walking: its connection (conn: sh_d = direction, distance) or its continuation ray (ray_d).  `conn` is the
+// lane's PathCtl::has_sh: a connection is walked from the retire point that follows its vertex until it is resolved.
+template <bool CONN, class LS> LR_DEV V3 ptrav_dir(bool conn, const LS& ls) {
+  if constexpr (CONN) return conn ? v3(ls.sh_d.v) : v3(ls.ray_d.v);
+  else return v3(ls.ray_d.v);
+}
 
-LR_DEV void ptrav_begin(PTrav& s, V3 d, float dist, bool shadow) {
-  s.d = d; s.dist = dist; s.shadow = shadow;
+LR_DEV void ptrav_begin(PTrav& s, V3 d) {
   s.t = 3.0e38f; s.prim = -1; s.occluded = false; s.cur = 0; s.sp = 0;
   {
 #pragma clang fp contract(fast)
@@ -472,8 +478,9 @@ LR_DEV bool ptrav_pop(const DevScene& sc, PTrav& s, const uint32_t* stk_n) {
   return false;
 }
 // one 4-wide node (trav_node): boxes only prune, so fused / approximate arithmetic is allowed here
-template <bool CONN>                                              // CONN = false: no lane ever walks a connection (integrator pt)
-LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
+template <bool CONN, class LS>                                    // CONN = false: no lane ever walks a connection (integrator pt)
+LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, const LS& ls, bool conn, uint32_t* stk_n) {
+  const V3 o = v3(ls.ray_o.v);
   const float4* n = sc.nodes + kNodeRows * (size_t)s.cur;
   float4 g = n[0], qa = n[1], qb = n[2], rc = n[3];
   float k0, k1, k2, k3;
@@ -485,7 +492,7 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n) {
     const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - o.x) * s.ix;
     const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - o.y) * s.iy;
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - o.z) * s.iz;
-    const float bound = __float_as_uint(qb.z) != 0u ? inf : ((CONN && s.shadow) ? s.dist + 2.0f * kEps : s.t);   // as trav_node
+    const float bound = __float_as_uint(qb.z) != 0u ? inf : ((CONN && conn) ? ls.sh_d.v.w + 2.0f * kEps : s.t);   // as trav_node
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
@@ -531,8 +538,9 @@ LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
 }
 // one leaf (trav_leaf): the primitive tests decide, exact arithmetic
-template <bool CONN>
-LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n) {
+template <bool CONN, class LS>
+LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, const uint32_t* stk_n) {
+  const V3 o = v3(ls.ray_o.v), d = ptrav_dir<CONN>(conn, ls);
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
   const float4* q = sc.prims + 3 * (size_t)first;
@@ -544,15 +552,15 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
     int id = (int)(idw & 0x7fffffffu);
     float t; bool hit;
 #if LR_LEAF_BRANCHFREE
-    if (idw >> 31) { V3 co = o - v3(q0); hit = sphere_test_co(co, sqr_norm(co), q1.y, s.d, &t); }
-    else hit = tri_test_bf(v3(q0), v3(q1), v3(q2), o, s.d, &t);
+    if (idw >> 31) { V3 co = o - v3(q0); hit = sphere_test_co(co, sqr_norm(co), q1.y, d, &t); }
+    else hit = tri_test_bf(v3(q0), v3(q1), v3(q2), o, d, &t);
 #else
-    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, s.d, &t);
-    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, s.d, &t);
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
 #endif
     if (!hit) continue;
-    if (CONN && s.shadow) {
-      float diff = t - s.dist;
+    if (CONN && conn) {
+      float diff = t - ls.sh_d.v.w;
       if (diff < -kEps) { s.occluded = true; return false; }
       if (diff > kEps) continue;
     }
@@ -568,8 +576,8 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, V3 o, const uint32_t* stk_n
 #ifndef LR_BURST_NEE
 #define LR_BURST_NEE 3
 #endif
-template <bool CONN>
-LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
+template <bool CONN, class LS>
+LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
   (void)dg;
 #pragma unroll 1
   for (int it = 0; it < (CONN ? LR_BURST_NEE : LR_BURST_PT); ++it) {
@@ -577,11 +585,11 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, V3 o, uint32_t* stk_n, boo
     const uint64_t bm = __ballot(nm);
     if (bm == 0) break;
     LR_DIAG_ONLY(unsigned long long t0 = __builtin_amdgcn_s_memtime();)
-    if (nm) go = ptrav_node<CONN>(sc, s, o, stk_n);
+    if (nm) go = ptrav_node<CONN>(sc, s, ls, conn, stk_n);
     LR_DIAG_ONLY(dg->node_steps += 1; dg->node_lanes += (unsigned)__builtin_popcountll(bm); dg->cyc_node += __builtin_amdgcn_s_memtime() - t0;)
   }
   LR_DIAG_ONLY(const uint64_t lm = __ballot(go && s.cur < 0); unsigned long long t1 = __builtin_amdgcn_s_memtime();)
-  if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, o, stk_n);
+  if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, ls, conn, stk_n);
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
@@ -626,36 +634,34 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
-  PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f), 0.0f, false);
-  bool has = false, fin = false;                                     // the lane has a ray in flight / its walk is over
+  PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f));
+  bool go = false;                                                   // the lane's walk is under way
   bool spare = false;
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
     // ================= retire point (converged) =================
+    // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, spare, has_sh, occluded.)
     // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
     if constexpr (NEE) {
-      const bool fs = has && fin && tr.shadow;
+      const bool fs = __float_as_int(ls.ray_o.v.w) >= 0 && !go && c.has_sh;
       if (__ballot(fs) != 0) {
         LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(fs));)
         if (fs) {
-          V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), tr.d, v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
+          V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), v3(ls.sh_d.v), v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
           ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
           c.has_sh = false;
-          ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
-          fin = false;
+          ptrav_begin(tr, v3(ls.ray_d.v));
+          go = true;
         }
         LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq;)
       }
     }
     // (b) continuation rays whose walk is over: the vertex
-    {
-      const bool fm = has && fin;                                      // (a) left only closest-hit walks with fin set
-      if (__ballot(fm) != 0) {
-        LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
-        path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, s_stat);
-        if (fm) { has = false; fin = false; }
-        LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
-      }
+    const bool fm = __float_as_int(ls.ray_o.v.w) >= 0 && !go;         // (a) left only closest-hit walks among these
+    if (__ballot(fm) != 0) {
+      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
+      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, s_stat);
+      LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
     {
@@ -667,32 +673,31 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
 #endif
       LR_DIAG_ONLY(dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;)
     }
-    // (d) every live lane without a ray starts its next one: the connection first, if its vertex left one
+    // (d) every lane with a path and no walk under way starts its next ray: the connection first, if its vertex left one
+    const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
     {
-      const bool start = !has && __float_as_int(ls.ray_o.v.w) >= 0;
+      const bool start = live && !go;
       stat_count(&s_stat[ST_SEGMENTS], __ballot(start));
       if constexpr (NEE) stat_count(&s_stat[ST_SHADOW], __ballot(start && c.has_sh));
       if (start) {
-        if (NEE && c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v), ls.sh_d.v.w, true);
-        else ptrav_begin(tr, v3(ls.ray_d.v), 0.0f, false);
-        has = true; fin = false;
+        if (NEE && c.has_sh) ptrav_begin(tr, v3(ls.sh_d.v));
+        else ptrav_begin(tr, v3(ls.ray_d.v));
+        go = true;
       }
     }
-    const uint64_t hm = __ballot(has);
+    const uint64_t hm = __ballot(live);
     if (hm == 0) break;
     // ================= walk until at most half of the wave's rays are still under way =================
     const int live_n = __builtin_popcountll(hm);
     const int thresh = live_n * LR_RETIRE_EIGHTHS / 8;
-    const V3 o = v3(ls.ray_o.v);
-    bool go = has && !fin;
+    const bool conn = NEE && c.has_sh;
 #ifdef LR_DIAG
     tq = __builtin_amdgcn_s_memtime(); dg.walks += 1; dg.walk_lanes += (unsigned)__builtin_popcountll(__ballot(go));
-    do { ptrav_burst<NEE>(sc, tr, o, stk_n, go, &dg); } while (__builtin_popcountll(__ballot(go)) > thresh);
+    do { ptrav_burst<NEE>(sc, tr, ls, conn, stk_n, go, &dg); } while (__builtin_popcountll(__ballot(go)) > thresh);
     dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq;
 #else
-    do { ptrav_burst<NEE>(sc, tr, o, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
+    do { ptrav_burst<NEE>(sc, tr, ls, conn, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
 #endif
-    fin = has && !go;
   }
 #ifdef LR_DIAG
   dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
