@@ -610,11 +610,20 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
                                 : (nee_k ? (const void*)k_path_tree<31u, true> : (const void*)k_path_tree<31u, false>);
       want_waves = path_tree_waves(nee_k);
       fused_stack = std::min(s.stack_depth, std::getenv("LR_STACK_LDS") ? stack_lds_limit() : kStackLdsFused);
-      fused_lds = (size_t)fused_stack * kBlock * 4 + (s.dev.cam.type == LR_CAMERA_THIN_LENS ? kSpareLensBytes : 0);
-      if (fused_lds > 48 * 1024) HIP_OK(hipFuncSetAttribute(fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
     }
     int fit = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fused_kernel, kBlock, fused_lds));
+    hipFuncAttributes fa; HIP_OK(hipFuncGetAttributes(&fa, fused_kernel));
+    for (;;) {                                                         // a scene class whose LDS need leaves a workgroup out gives up stack entries (down to 8) for it
+      fused_lds = (size_t)fused_stack * kBlock * 4 + (s.dev.n_flat == 0 && s.dev.cam.type == LR_CAMERA_THIN_LENS ? kSpareLensBytes : 0);
+      if (fused_lds > 48 * 1024) HIP_OK(hipFuncSetAttribute(fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+      HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fused_kernel, kBlock, fused_lds));
+      // the CU hands out its 160 KB in 1280-B granules (measured: 27 104 B per workgroup ran five per CU where the runtime
+      // reported six, and the sixth of every CU waited for a slot: -6 %), the occupancy query rounds less
+      const size_t granule = 1280, per_wg = (fa.sharedSizeBytes + fused_lds + granule - 1) / granule * granule;
+      fit = std::min<int>(fit, (int)((160 * 1024) / std::max<size_t>(per_wg, granule)));
+      if (fit >= want_waves || fused_stack <= 8 || s.dev.n_flat > 0 || std::getenv("LR_STACK_LDS")) break;
+      --fused_stack;
+    }
     if (fit < 1) fail(LR_EUNSUPPORTED, "the fused kernel does not fit a compute unit");
     if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lumilly_hip] fused kernel: %d workgroups per CU fit (%d wanted), %zu B of dynamic LDS\n", fit, want_waves, fused_lds);
     n_slots = (uint32_t)(s.n_cus * std::min(fit, want_waves) * kBlock);
