@@ -27,6 +27,10 @@
 #pragma once
 #include "lr_kernels.h"
 
+#ifndef LR_PUSH_BRANCHFREE
+#define LR_PUSH_BRANCHFREE 1
+#endif
+
 namespace lr {
 
 typedef RowVec __attribute__((address_space(3))) LdsRow;
@@ -513,6 +517,17 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, const LS& ls, bool conn, ui
     int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
     if (n_hit == 0) return ptrav_pop(sc, s, stk_n);
     order2(k0, r0, k1, r1); order2(k2, r2, k3, r3); order2(k0, r0, k2, r2); order2(k1, r1, k3, r3); order2(k1, r1, k2, r2);
+#if LR_PUSH_BRANCHFREE
+    // the far children go on the stack far-first.  Entries at and above the new top are dead, so while three more fit the LDS
+    // part every lane stores three words -- which ones is a select on n_hit -- instead of walking three blocks of predicated
+    // stores with an LDS-or-spill branch in each (lanes of one wave differ in n_hit, so the wave used to walk them all)
+    if (s.sp + 3 <= sc.stack_lds) {
+      lds_u32* e = (lds_u32*)stk_n + s.sp * kBlock + threadIdx.x;
+      e[0] = (uint32_t)(n_hit == 4 ? r3 : (n_hit == 3 ? r2 : r1));
+      e[kBlock] = (uint32_t)(n_hit == 4 ? r2 : r1);
+      e[2 * kBlock] = (uint32_t)r1;
+    } else
+#endif
     if (n_hit == 4) { stack_store(sc, stk_n, s.sp, (uint32_t)r3); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 2, (uint32_t)r1); }
     else if (n_hit == 3) { stack_store(sc, stk_n, s.sp, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r1); }
     else if (n_hit == 2) { stack_store(sc, stk_n, s.sp, (uint32_t)r1); }
@@ -537,35 +552,60 @@ LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   *t_out = t;
   return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
 }
-// one leaf (trav_leaf): the primitive tests decide, exact arithmetic
+// one primitive of a leaf against the lane's ray; true = a connection found its occluder (the walk is over)
+template <bool CONN, class LS>
+LR_DEV bool ptrav_prim(PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
+  uint32_t idw = __float_as_uint(q0.w);
+  int id = (int)(idw & 0x7fffffffu);
+  float t; bool hit;
+#if LR_LEAF_BRANCHFREE
+  if (idw >> 31) { V3 co = o - v3(q0); hit = sphere_test_co(co, sqr_norm(co), q1.y, d, &t); }
+  else hit = tri_test_bf(v3(q0), v3(q1), v3(q2), o, d, &t);
+#else
+  if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+  else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
+#endif
+  if (!hit) return false;
+  if (CONN && conn) {
+    float diff = t - ls.sh_d.v.w;
+    if (diff < -kEps) { s.occluded = true; return true; }
+    if (diff > kEps) return false;
+  }
+  if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }
+  return false;
+}
+// one leaf (trav_leaf): the primitive tests decide, exact arithmetic.  The rows of the next primitive are requested before the
+// current one is tested; the loop is written two primitives long so that the two row sets swap roles instead of being copied
+// (the rotating form spent 19 v_mov per primitive on it, a fifth of the loop)
+#ifndef LR_LEAF_UNROLL2
+#define LR_LEAF_UNROLL2 1
+#endif
 template <bool CONN, class LS>
 LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, const uint32_t* stk_n) {
   const V3 o = v3(ls.ray_o.v), d = ptrav_dir<CONN>(conn, ls);
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
   const float4* q = sc.prims + 3 * (size_t)first;
+#if LR_LEAF_UNROLL2
+  float4 a0 = q[0], a1 = q[1], a2 = q[2], b0 = a0, b1 = a1, b2 = a2;
+  for (uint32_t k = 0; ; k += 2) {
+    const bool more1 = k + 1 < count;
+    if (more1) { b0 = q[3 * k + 3]; b1 = q[3 * k + 4]; b2 = q[3 * k + 5]; }
+    if (ptrav_prim<CONN>(s, ls, conn, o, d, a0, a1, a2)) return false;
+    if (!more1) break;
+    const bool more2 = k + 2 < count;
+    if (more2) { a0 = q[3 * k + 6]; a1 = q[3 * k + 7]; a2 = q[3 * k + 8]; }
+    if (ptrav_prim<CONN>(s, ls, conn, o, d, b0, b1, b2)) return false;
+    if (!more2) break;
+  }
+#else
   float4 n0 = q[0], n1 = q[1], n2 = q[2];
   for (uint32_t k = 0; k < count; ++k) {
     float4 q0 = n0, q1 = n1, q2 = n2;
     if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
-    uint32_t idw = __float_as_uint(q0.w);
-    int id = (int)(idw & 0x7fffffffu);
-    float t; bool hit;
-#if LR_LEAF_BRANCHFREE
-    if (idw >> 31) { V3 co = o - v3(q0); hit = sphere_test_co(co, sqr_norm(co), q1.y, d, &t); }
-    else hit = tri_test_bf(v3(q0), v3(q1), v3(q2), o, d, &t);
-#else
-    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
-    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
-#endif
-    if (!hit) continue;
-    if (CONN && conn) {
-      float diff = t - ls.sh_d.v.w;
-      if (diff < -kEps) { s.occluded = true; return false; }
-      if (diff > kEps) continue;
-    }
-    if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }
+    if (ptrav_prim<CONN>(s, ls, conn, o, d, q0, q1, q2)) return false;
   }
+#endif
   return ptrav_pop(sc, s, stk_n);
 }
 // node steps in a row before the lanes that reached a leaf get their turn: 2 in the pt kernel (7 waves per SIMD; 100k-triangle
