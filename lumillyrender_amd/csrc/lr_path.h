@@ -52,7 +52,7 @@ LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int
 
 // LR_DIAG build: wave-uniform phase counters of k_path_tree (calls, lanes, cycles), printed by lr_render
 struct PathDiag { unsigned long long cyc_total, cyc_resolve, n_resolve, l_resolve, cyc_vertex, n_vertex, l_vertex, cyc_finish, n_finish, l_finish,
-                  cyc_walk, walks, walk_lanes, node_steps, node_lanes, cyc_node, leaf_steps, leaf_lanes, cyc_leaf, leaf_prims, n_batch, l_batch, n_forced, cyc_batch; };
+                  cyc_walk, walks, walk_lanes, node_steps, node_lanes, cyc_node, leaf_steps, leaf_lanes, cyc_leaf, leaf_prims, n_batch, l_batch, n_forced, cyc_batch, leaf_prims_max; };
 
 // ---- wave-level work-item pool: a range of reserved item ids in scalar registers ----
 // Four LDS words per wave {next reserved item, how many are left, the dispenser has run out, -}: only the spare batch touches
@@ -628,7 +628,15 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, u
     if (nm) go = ptrav_node<CONN>(sc, s, ls, conn, stk_n);
     LR_DIAG_ONLY(dg->node_steps += 1; dg->node_lanes += (unsigned)__builtin_popcountll(bm); dg->cyc_node += __builtin_amdgcn_s_memtime() - t0;)
   }
-  LR_DIAG_ONLY(const uint64_t lm = __ballot(go && s.cur < 0); unsigned long long t1 = __builtin_amdgcn_s_memtime();)
+#ifdef LR_DIAG
+  const uint64_t lm = __ballot(go && s.cur < 0);
+  if (lm) {
+    uint32_t cnt = (go && s.cur < 0) ? ((uint32_t)~s.cur & 7u) : 0u, mx = cnt, sm = cnt;
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64)); sm += (uint32_t)__shfl_xor((int)sm, off, 64); }
+    dg->leaf_prims_max += mx; dg->leaf_prims += sm;
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
   if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, ls, conn, stk_n);
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }

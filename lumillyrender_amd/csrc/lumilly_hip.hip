@@ -911,10 +911,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         pc(d.cyc_vertex), per(d.l_vertex, d.n_vertex), per(d.cyc_vertex, d.n_vertex),
         per(d.n_batch, d.n_finish), per(d.l_batch, d.n_batch), per(d.cyc_batch, d.n_batch), pc(d.cyc_batch), 100.0 * per(d.n_forced, d.n_batch));
     if (d.walks && d.node_steps) std::fprintf(stderr, "[LR_DIAG] k_path_tree wave cycles: resolve %.1f%% (%.1f lanes, %.0f cyc) vertex %.1f%% (%.1f lanes, %.0f cyc) finish %.1f%% (%.1f lanes, %.0f cyc) "
-        "walk %.1f%% [node %.1f%% (%.1f lanes, %.0f cyc/step) leaf %.1f%% (%.1f lanes, %.0f cyc/step)] other %.1f%%; per walk: %.1f lanes in, %.1f node steps, %.1f leaf steps; spare batches %.3f per retire point (%.1f lanes, %.0f cyc, %.1f%% of the cycles, forced %.1f%%)\n",
+        "walk %.1f%% [node %.1f%% (%.1f lanes, %.0f cyc/step) leaf %.1f%% (%.1f lanes, %.0f cyc/step, %.2f primitives per lane, longest %.2f: %.1f lanes per test)] other %.1f%%; per walk: %.1f lanes in, %.1f node steps, %.1f leaf steps; spare batches %.3f per retire point (%.1f lanes, %.0f cyc, %.1f%% of the cycles, forced %.1f%%)\n",
         pc(d.cyc_resolve), per(d.l_resolve, d.n_resolve), per(d.cyc_resolve, d.n_resolve), pc(d.cyc_vertex), per(d.l_vertex, d.n_vertex), per(d.cyc_vertex, d.n_vertex),
         pc(d.cyc_finish), per(d.l_finish, d.n_finish), per(d.cyc_finish, d.n_finish), pc(d.cyc_walk), pc(d.cyc_node), per(d.node_lanes, d.node_steps), per(d.cyc_node, d.node_steps),
-        pc(d.cyc_leaf), per(d.leaf_lanes, d.leaf_steps), per(d.cyc_leaf, d.leaf_steps),
+        pc(d.cyc_leaf), per(d.leaf_lanes, d.leaf_steps), per(d.cyc_leaf, d.leaf_steps), per(d.leaf_prims, d.leaf_lanes), per(d.leaf_prims_max, d.leaf_steps), per(d.leaf_prims, d.leaf_prims_max),
         pc(d.cyc_total - d.cyc_resolve - d.cyc_vertex - d.cyc_finish - d.cyc_walk), per(d.walk_lanes, d.walks), per(d.node_steps, d.walks), per(d.leaf_steps, d.walks),
         per(d.n_batch, d.n_finish), per(d.l_batch, d.n_batch), per(d.cyc_batch, d.n_batch), pc(d.cyc_batch), 100.0 * per(d.n_forced, d.n_batch));
   }
