@@ -124,6 +124,36 @@ def test_fused_pipeline_is_bit_identical_on_tree_scenes(dev, oracle, name, spp):
     scene.close(); s2.close()
 
 
+@pytest.mark.parametrize("name", ["mesh-box.toml", "ibl-lens.toml"])
+def test_spare_camera_samples_edge_sizes_on_tree_scenes(dev, name):
+    """The finish stage of the fused kernels hands every lane its next camera sample from LDS (path_spare_batch /
+    path_consume, thin lens: with the aperture point).  One pixel, fewer work items than lanes of a wave, chunk lengths that do
+    not divide spp, chunk ends inside a batch, and a three-rank tile split: every sample exactly once (device counter), film
+    equal to the streaming pipeline's bit for bit."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    from lumillyrender_amd import abi, host
+    for (w, h, spp) in ((1, 1, 1), (1, 1, 19), (5, 3, 17), (40, 30, 33), (64, 2, 9)):
+        desc = load(name, w, h)
+        scene = dev.Scene(desc)
+        a = scene.render(desc.render_params(spp=spp, seed=11, flags=abi.LR_FLAG_FUSED))
+        st = scene.stats()
+        assert st.pipeline == 2 and st.samples == w * h * spp, (name, w, h, spp, st.samples)
+        b = scene.render(desc.render_params(spp=spp, seed=11, flags=abi.LR_FLAG_STREAMING))
+        assert np.array_equal(a, b, equal_nan=True), (name, w, h, spp)
+        scene.close()
+    desc = load(name, 72, 40)
+    scene = dev.Scene(desc)
+    p = desc.render_params(spp=12, seed=2, flags=abi.LR_FLAG_FUSED)
+    whole = scene.render(p)
+    out = np.zeros_like(whole)
+    for rank in range(3):
+        tiles, n = host.tiles(72, 40, 8, rank, 3)
+        scene.render(p, tiles, n, out=out)
+    assert np.array_equal(whole, out, equal_nan=True)
+    scene.close()
+
+
 def test_fused_pipeline_on_random_tree_scenes(dev, oracle):
     """Random scenes with more than 32 primitives (spheres and transformed quads, all five BSDFs, area lights or sky, the
     three cameras, both integrators) through k_path_tree<31>: film equal to the streaming pipeline's bit for bit, equal NaN
