@@ -1771,7 +1771,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
     }
     LR_TICK(2)
     __syncthreads();
-    LR_TICK(0)
+    LR_TICK(1)
     // ---- phase 2: one BSDF-specialised body per list ----
     // nobody draws work items in this phase, so the last thread (its wave has the least shade work: the lists fill
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
@@ -1784,7 +1784,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
     if ((MTS & 16u) && (mt_mask & 16u)) resident_shade_list<4, RB, LT>(sc, st, rp, lists + lpos(4) * RB, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     LR_TICK(3)
     __syncthreads();
-    LR_TICK(0)
+    LR_TICK(5)
     // ---- phase 3: shadow rays of this iteration, and -- on the waves the shadow list leaves idle -- the
     // finish pass: every path that ended in phase 1 (miss) or phase 2 (roulette) is folded into its chunk
     // sum and its slot starts the next camera sample.  Dense waves instead of ~20 % of the lanes of every
@@ -1828,7 +1828,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   }
 #ifdef LR_STAMP
   // diagnostic build only: lane 0 of every wave adds its cycle shares to the tail of the stats buffer
-  if (lane_id() == 0) for (int i = 0; i < 5; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
+  if (lane_id() == 0) for (int i = 0; i < 6; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
 #endif
   stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
   stat_accumulate(&s_stat[ST_SHADOW], n_shq);

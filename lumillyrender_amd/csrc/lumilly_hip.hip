@@ -879,9 +879,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   {
     unsigned long long tk[8];
     HIP_OK(hipMemcpy(tk, s.stats_dev.p + (size_t)kStatShards * kStatStride, sizeof(tk), hipMemcpyDeviceToHost));
-    double tot = 0; for (int i = 0; i < 5; ++i) tot += (double)tk[i];
-    std::fprintf(stderr, "[LR_STAMP] wave-cycle shares: barrier-wait %.1f%%  pool/zero %.1f%%  trace %.1f%%  shade %.1f%%  shadow %.1f%%\n",
-                 100 * tk[0] / tot, 100 * tk[1] / tot, 100 * tk[2] / tot, 100 * tk[3] / tot, 100 * tk[4] / tot);
+    double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)tk[i];
+    std::fprintf(stderr, "[LR_STAMP] k_resident wave-cycle shares: trace %.1f%% + barrier %.1f%%  shade %.1f%% + barrier %.1f%%  shadow / finish %.1f%% + barrier %.1f%%\n",
+                 100 * tk[2] / tot, 100 * tk[1] / tot, 100 * tk[3] / tot, 100 * tk[5] / tot, 100 * tk[4] / tot, 100 * tk[0] / tot);
   }
 #endif
 #ifdef LR_DIAG
