@@ -8,7 +8,7 @@
 //
 //   finish     main.rs:92-121 in two halves: a lane whose path ended folds its radiance into the chunk sum and installs the
 //              camera sample it holds ready in LDS (path_consume); next work item + RNG + camera.rs sample() for every lane
-//              that lacks such a spare run as a batch at 20+ of 64 lanes (path_spare_batch)
+//              that lacks such a spare run as a batch at 20+ of 64 lanes (path_spare_batch; the flat kernel queues two per lane)
 //   trace      closest hit of the lane's ray AND, in the same pass over the primitives, the visibility test of the
 //              direct-light connection the previous vertex left behind: both rays leave the same point (scene.rs:94-97,
 //              112-117), so per triangle  tv = o - p0,  qv = tv x e1  and  e2 . qv  (17 of the 57 operations of
@@ -190,28 +190,49 @@ constexpr int kRecStride = 5;          // float4 rows per staged shading record:
 // item's samples are still folded in order by one lane, so the film does not.  (First built with the spares in global memory,
 // three 16-B rows: a round trip through the vector-memory path of a tree scene costs 3000+ cycles, -5 %.)
 #ifndef LR_SPARE_BATCH
-#define LR_SPARE_BATCH 24
+#define LR_SPARE_BATCH 24              // one spare per lane (tree kernels): produce when this many lanes lack theirs
 #endif
+#ifndef LR_SPARE_BATCH2
+#define LR_SPARE_BATCH2 40             // two spares per lane (flat kernel, pinhole): produce when this many lanes hold fewer than two
+#endif
+// With ONE spare per lane most batches are forced by a lane that ends again before LR_SPARE_BATCH others have, and run at 21-28
+// lanes.  The flat kernel has LDS for a SECOND spare per lane (not beside the thin lens' aperture points, and not the tree
+// kernels beside their stack): a two-entry queue, the batch adds one entry to every lane that holds fewer than two.
 constexpr uint32_t kNoItem = 0xffffffffu;     // spare of a lane that found pool and dispenser empty: consuming it retires the lane
 struct SpareLds {
-  LdsRow* acc; uint32_t* end;                 // the sample in flight: chunk sum + work item, chunk end
-  LdsRow* dir;                                // the spare: camera ray direction, weight
+  LdsRow* acc;                                // the sample in flight: chunk sum + work item
+  uint32_t* end;                              // chunk end of the NEWEST sample the lane was assigned (in flight or queued)
+  LdsRow* dir;                                // the spares [D][kBlock]: camera ray direction, weight
   uint32_t *pix, *item, *smp;                 //            pixel, work item, sample number
   float *lu, *lv;                             //            thin lens: the aperture point in the lens plane (null otherwise)
   uint32_t wave_base;                         // threadIdx.x of the wave's lane 0
   uint32_t* pool;                             // this wave's kPoolWords
 };
 constexpr size_t kSpareLensBytes = 2 * kBlock * sizeof(float);
+// the lane's queue of D spares in one register: entries held (bits 0-1), slot of the oldest (bit 2).  A retired lane stays "full".
+template <int D> LR_DEV uint32_t sq_count(uint32_t sq) { return sq & 3u; }
+template <int D> LR_DEV uint32_t sq_head(uint32_t sq) { return D == 1 ? 0u : (sq >> 2) & 1u; }
+template <int D> LR_DEV uint32_t sq_make(uint32_t count, uint32_t head) { return D == 1 ? count : (count | (head << 2)); }
 
-// main.rs:92-121, first half: which sample follows the one the lane has in flight (next of the chunk, or the first of a new
-// work item from the wave's pool), its camera ray (camera.rs sample()).  Whole (converged) wave; `want` = the lane lacks a spare.
-template <class LS>
+// main.rs:92-121, first half: which sample follows the newest one the lane was assigned (next of the chunk, or the first of a
+// new work item from the wave's pool), its camera ray (camera.rs sample()); appended to the lane's queue.  Whole (converged)
+// wave; `want` = the lane holds fewer than D spares.
+template <int D, class LS>
 LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevParams& rp, const LS& ls, const PathCtl& c,
-                             const SpareLds& sp, bool want) {
+                             const SpareLds& sp, bool want, uint32_t& sq) {
   const uint32_t tid = tid_of(sp.wave_base);
-  uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w) + 1u;
+  const uint32_t count = sq_count<D>(sq), head = sq_head<D>(sq);
+  const uint32_t tail = D == 1 ? 0u : (head + count) & 1u;            // where the new entry goes
+  uint32_t pixel = __float_as_uint(ls.thr.v.w), sample = __float_as_uint(ls.rad.v.w);
   uint32_t item = 0, end = 0;
-  if (want && !c.fresh) { item = __float_as_uint(sp.acc[tid].w); end = sp.end[tid]; }
+  if (want && !c.fresh) {
+    item = __float_as_uint(sp.acc[tid].w); end = sp.end[tid];
+    if (D > 1 && count > 0) {                                          // the newest assigned sample is the queued one
+      const uint32_t nw = (tail ^ 1u) * kBlock + tid;
+      pixel = sp.pix[nw]; sample = sp.smp[nw]; item = sp.item[nw];
+    }
+  }
+  sample += 1u;
   const bool need_item = want && (c.fresh || sample >= end);
   const uint64_t nm = __ballot(need_item);
   bool retired = false;
@@ -238,6 +259,8 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
         uint32_t chunk = item / n_pix, rank = item - chunk * n_pix;
         pixel = st.rank_pixel[rank];
         sample = chunk * st.chunk_spp;
+        uint32_t e = sample + st.chunk_spp;
+        sp.end[tid] = e > (uint32_t)rp.spp ? (uint32_t)rp.spp : e;
       }
     }
     // advance the pool by what was handed out (wave-uniform)
@@ -246,82 +269,75 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
     if (lane_id() == 0) { sp.pool[0] = r0; sp.pool[1] = a0; sp.pool[2] = dry; }
   }
   if (want) {
+    const uint32_t at = tail * kBlock + tid;
     if (retired) {
-      sp.item[tid] = kNoItem;
+      sp.item[at] = kNoItem;
+      sq = sq_make<D>((uint32_t)D, head);                              // full: the marker is the last entry the lane will ever get
     } else {
       Draw4 d0 = rng_block(rp.seed, pixel, sample, 0u);
       const uint32_t res_w = (uint32_t)fresh_s(sc.cam.res_w);
       uint32_t y = pixel / res_w, x = pixel - y * res_w;
       V3 o, d; float g, lens[2] = {0.0f, 0.0f};
       camera_sample(sc.cam, (int)x, (int)y, d0, &o, &d, &g, lens);
-      sp.dir[tid] = (RowVec){d.x, d.y, d.z, g};
-      sp.pix[tid] = pixel; sp.item[tid] = item; sp.smp[tid] = sample;
-      if (sp.lu) { sp.lu[tid] = lens[0]; sp.lv[tid] = lens[1]; }
+      sp.dir[at] = (RowVec){d.x, d.y, d.z, g};
+      sp.pix[at] = pixel; sp.item[at] = item; sp.smp[at] = sample;
+      if (sp.lu) { sp.lu[at] = lens[0]; sp.lv[at] = lens[1]; }
+      sq = sq_make<D>(count + 1u, head);
     }
   }
 }
 
-// main.rs:92-121, second half, for the lanes in `fin` (their sample ended, or they have no item yet; each has a spare): fold the
-// radiance into the chunk sum, write the sum out if the spare belongs to another work item, install the spare.  Returns
-// whether the lane retired.
-template <class LS>
-LR_DEV bool path_consume(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c, const SpareLds& sp, bool fin, uint32_t* s_stat) {
+// main.rs:92-121, second half, for the lanes in `fin` (their sample ended, or they have no item yet; each holds a spare): fold the
+// radiance into the chunk sum, write the sum out if the oldest spare belongs to another work item, install that spare.
+template <int D, class LS>
+LR_DEV void path_consume(const DevScene& sc, const DevState& st, LS& ls, PathCtl& c, const SpareLds& sp, bool fin, uint32_t& sq, uint32_t* s_stat) {
   const uint32_t tid = tid_of(sp.wave_base);
   stat_count(&s_stat[ST_SAMPLES], __ballot(fin && c.finished));
-  bool retired = false;
   if (fin) {
-    const uint32_t item2 = sp.item[tid];
+    const uint32_t head = sq_head<D>(sq), at = head * kBlock + tid;
+    const uint32_t item2 = sp.item[at];
     V3 sum = v3(0, 0, 0);
-    bool other = true;
     if (c.finished) {
       float4 a = row4(sp.acc[tid]);
       V3 delta = v3(ls.rad.v);
       if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (delta * ls.ray_d.v.w) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
       sum = v3(a) + delta;
-      other = item2 != __float_as_uint(a.w);
-      if (other) { st.partial[__float_as_uint(a.w)] = make_float4(sum.x, sum.y, sum.z, 0.0f); sum = v3(0, 0, 0); }
+      if (item2 != __float_as_uint(a.w)) { st.partial[__float_as_uint(a.w)] = make_float4(sum.x, sum.y, sum.z, 0.0f); sum = v3(0, 0, 0); }
     }
     if (item2 == kNoItem) {
-      retired = true;
       ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
+      sq = sq_make<D>((uint32_t)D, 0u);                                // retired: never short of spares again
     } else {
-      const float4 dg = row4(sp.dir[tid]);
-      const uint32_t sample = sp.smp[tid];
+      const float4 dg = row4(sp.dir[at]);
+      const uint32_t sample = sp.smp[at];
       sp.acc[tid] = (RowVec){sum.x, sum.y, sum.z, __uint_as_float(item2)};
-      if (other) { uint32_t end = sample + st.chunk_spp; sp.end[tid] = end > (uint32_t)rp.spp ? (uint32_t)rp.spp : end; }
-      V3 o = camera_origin(sc.cam, sp.lu ? sp.lu[tid] : 0.0f, sp.lv ? sp.lv[tid] : 0.0f);
+      V3 o = camera_origin(sc.cam, sp.lu ? sp.lu[at] : 0.0f, sp.lv ? sp.lv[at] : 0.0f);
       ls.ray_o.v = make_float4(o.x, o.y, o.z, __int_as_float(0));
       ls.ray_d.v = dg;
-      ls.thr.v = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sp.pix[tid]));
+      ls.thr.v = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sp.pix[at]));
       ls.rad.v = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sample));
+      sq = sq_make<D>(sq_count<D>(sq) - 1u, head ^ 1u);
     }
     c.finished = false; c.fresh = false;
   }
-  return retired;
 }
 
 // The finish stage of both fused kernels (converged wave): consume, produce spares where the wave is short of them, and
-// consume again for the lanes that had none.  `spare` = the lane has one (retired lanes: true, they never want another).
-template <class LS>
+// consume again for the lanes that held none.  `sq` = the lane's queue of D spares.
+template <int D, class LS>
 LR_DEV void path_finish_spares(const DevScene& sc, const DevState& st, const DevParams& rp, LS& ls, PathCtl& c,
-                               const SpareLds& sp, bool& spare, uint32_t* s_stat, PathDiag* dg = nullptr) {
+                               const SpareLds& sp, uint32_t& sq, uint32_t* s_stat, PathDiag* dg = nullptr) {
   (void)dg;
-  const bool fin1 = (c.finished || c.fresh) && spare;
-  if (__ballot(fin1) != 0) {
-    const bool r = path_consume(sc, st, rp, ls, c, sp, fin1, s_stat);
-    if (fin1) spare = r;
-  }
+  const bool fin1 = (c.finished || c.fresh) && sq_count<D>(sq) != 0u;
+  if (__ballot(fin1) != 0) path_consume<D>(sc, st, ls, c, sp, fin1, sq, s_stat);
   const bool unserved = c.finished || c.fresh;
   const uint64_t um = __ballot(unserved);
-  if (um != 0 || (int)__builtin_popcountll(__ballot(!spare)) >= LR_SPARE_BATCH) {
-    LR_DIAG_ONLY(unsigned long long tb = __builtin_amdgcn_s_memtime(); if (dg) { dg->n_batch += 1; dg->l_batch += (unsigned)__builtin_popcountll(__ballot(!spare)); dg->n_forced += um != 0; })
-    path_spare_batch(sc, st, rp, ls, c, sp, !spare);
+  const bool want = sq_count<D>(sq) < (uint32_t)D;
+  if (um != 0 || (int)__builtin_popcountll(__ballot(want)) >= (D == 1 ? LR_SPARE_BATCH : LR_SPARE_BATCH2)) {
+    LR_DIAG_ONLY(unsigned long long tb = __builtin_amdgcn_s_memtime(); if (dg) { dg->n_batch += 1; dg->l_batch += (unsigned)__builtin_popcountll(__ballot(want)); dg->n_forced += um != 0; })
+    path_spare_batch<D>(sc, st, rp, ls, c, sp, want, sq);
     LR_DIAG_ONLY(if (dg) dg->cyc_batch += __builtin_amdgcn_s_memtime() - tb;)
-    spare = true;
-    if (um != 0) {
-      const bool r = path_consume(sc, st, rp, ls, c, sp, unserved, s_stat);
-      if (unserved) spare = r;
-    }
+    if (um != 0) path_consume<D>(sc, st, ls, c, sp, unserved, sq, s_stat);
   }
   c.finished = false; c.fresh = false;                               // (every such lane was served: nothing of these crosses the walk)
 }
@@ -360,16 +376,17 @@ LR_DEV void path_vertex(const DevScene& sc, const DevParams& rp, LS& ls, PathCtl
 // Flat scenes (<= kFlatMax primitives): every lane tests every primitive, rows through the scalar cache (traverse_flat).
 // Nothing in the loop diverges except the stages' own lane masks.
 // =====================================================================================================================
-template <uint32_t MTS>
+// D: spares per lane (2 unless the camera is a thin lens: its aperture points leave no room for the second set)
+template <uint32_t MTS, int D>
 __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc, DevState st, DevParams rp, const float4* __restrict__ flat_prims) {
   __shared__ RowVec s_rec[kFlatMax * kRecStride];
   __shared__ RowVec s_emit[kFlatMax * 3];
-  __shared__ RowVec s_acc[kBlock], s_sdir[kBlock];
-  __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
-  __shared__ float s_lens[2 * kBlock];
+  __shared__ RowVec s_acc[kBlock], s_sdir[D * kBlock];
+  __shared__ uint32_t s_end[kBlock], s_spix[D * kBlock], s_sitem[D * kBlock], s_ssmp[D * kBlock];
+  __shared__ float s_lens[D == 1 ? 2 * kBlock : 1];
   __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   const uint32_t tid = threadIdx.x;
-  const bool lens = sc.cam.type == LR_CAMERA_THIN_LENS;
+  const bool lens = D == 1 && sc.cam.type == LR_CAMERA_THIN_LENS;    // (the host picks D = 1 for a thin lens)
   const SpareLds sp = {(LdsRow*)s_acc, s_end, (LdsRow*)s_sdir, s_spix, s_sitem, s_ssmp, lens ? s_lens : nullptr, lens ? s_lens + kBlock : nullptr,
                        uniform(threadIdx.x), s_pool + kPoolWords * (uniform(threadIdx.x) >> 6)};
   if (tid < ST_COUNT) s_stat[tid] = 0;
@@ -390,16 +407,16 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
-  bool spare = false;
+  uint32_t sq = 0;                                                   // the lane's queue of spares (sq_count / sq_head)
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
     // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
 #ifdef LR_DIAG
     tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));
-    path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat, &dg);
+    path_finish_spares<D>(sc, st, rp, ls, c, sp, sq, s_stat, &dg);
     dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;
 #else
-    path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat);
+    path_finish_spares<D>(sc, st, rp, ls, c, sp, sq, s_stat);
 #endif
     const bool live = __float_as_int(ls.ray_o.v.w) >= 0;
     const uint64_t lm = __ballot(live);
@@ -684,11 +701,11 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
   PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f));
   bool go = false;                                                   // the lane's walk is under way
-  bool spare = false;
+  uint32_t sq = 0;                                                   // the lane's queue of one spare
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
     // ================= retire point (converged) =================
-    // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, spare, has_sh, occluded.)
+    // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, the spare count, has_sh, occluded.)
     // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
     if constexpr (NEE) {
       const bool fs = __float_as_int(ls.ray_o.v.w) >= 0 && !go && c.has_sh;
@@ -715,9 +732,9 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     {
       LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));)
 #ifdef LR_DIAG
-      path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat, &dg);
+      path_finish_spares<1>(sc, st, rp, ls, c, sp, sq, s_stat, &dg);
 #else
-      path_finish_spares(sc, st, rp, ls, c, sp, spare, s_stat);
+      path_finish_spares<1>(sc, st, rp, ls, c, sp, sq, s_stat);
 #endif
       LR_DIAG_ONLY(dg.cyc_finish += __builtin_amdgcn_s_memtime() - tq;)
     }

@@ -601,7 +601,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint32_t only = mt_mask | 1u;                                // the kernels are instantiated for the BASELINE material sets and for "anything"
     int want_waves;
     if (s.dev.n_flat > 0) {
-      fused_kernel = mt_mask == 1u ? (const void*)k_path_flat<1u> : (only == 9u ? (const void*)k_path_flat<9u> : (const void*)k_path_flat<31u>);
+      if (s.dev.cam.type == LR_CAMERA_THIN_LENS)                       // one spare camera sample per lane beside the aperture points, two otherwise
+        fused_kernel = mt_mask == 1u ? (const void*)k_path_flat<1u, 1> : (only == 9u ? (const void*)k_path_flat<9u, 1> : (const void*)k_path_flat<31u, 1>);
+      else
+        fused_kernel = mt_mask == 1u ? (const void*)k_path_flat<1u, 2> : (only == 9u ? (const void*)k_path_flat<9u, 2> : (const void*)k_path_flat<31u, 2>);
       want_waves = LR_PATH_WAVES;
     } else {
       const bool nee_k = rp_in.integrator == LR_INTEGRATOR_PT_DIRECT;  // (a pt-direct scene without emitters runs the NEE kernel: the branch is then never taken)

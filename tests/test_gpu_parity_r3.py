@@ -99,6 +99,28 @@ def test_fused_pipeline_edge_sizes(dev):
     scene.close()
 
 
+def test_flat_fused_kernel_spare_queues(dev, oracle):
+    """k_path_flat keeps two spare camera samples per lane (one beside a thin lens' aperture points; the host picks the
+    instantiation).  Both queue depths, frames with fewer work items than lanes and chunk lengths that do not divide spp: every
+    sample once, film equal to the resident pipeline's bit for bit and within tolerance of the oracle."""
+    from lumillyrender_amd import abi
+    lens = lambda t: t.replace('type = "ideal-pinhole"\nfov = 39.3077', 'type = "thin-lens"\nfov = 39.3077\nfocus-distance = 800\nf-number = 2.8')
+    for edit in (None, lens):
+        for (w, h, spp) in ((2, 1, 5), (33, 17, 19), (96, 64, 24)):
+            desc = load("cbox-spheres.toml", w, h, edit)
+            assert edit is None or "thin-lens" in lens(open(scene_path("cbox-spheres.toml")).read())
+            scene = dev.Scene(desc)
+            a = scene.render(desc.render_params(spp=spp, seed=21, flags=abi.LR_FLAG_FUSED))
+            st = scene.stats()
+            assert st.pipeline == 2 and st.samples == w * h * spp, (w, h, spp, st.samples)
+            b = scene.render(desc.render_params(spp=spp, seed=21, flags=abi.LR_FLAG_RESIDENT))
+            assert np.array_equal(a, b), (edit is not None, w, h, spp)
+            if (w, h) == (33, 17):
+                ref = oracle.render(desc, desc.render_params(spp=spp, seed=21))
+                assert float(np.nanmax(np.abs(a - ref))) < TOL
+            scene.close()
+
+
 @pytest.mark.parametrize("name,spp", [("mesh-box.toml", 24), ("ibl-lens.toml", 16)])
 def test_fused_pipeline_is_bit_identical_on_tree_scenes(dev, oracle, name, spp):
     """k_path_tree: the lane walks its own connection and continuation rays through the 4-wide tree and is shaded at the
