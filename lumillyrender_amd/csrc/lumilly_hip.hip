@@ -620,8 +620,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       fused_lds = (size_t)fused_stack * kBlock * 4 + (s.dev.n_flat == 0 && s.dev.cam.type == LR_CAMERA_THIN_LENS ? kSpareLensBytes : 0);
       if (fused_lds > 48 * 1024) HIP_OK(hipFuncSetAttribute(fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
       HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fused_kernel, kBlock, fused_lds));
-      // the CU hands out its 160 KB in 1280-B granules (measured: 27 104 B per workgroup ran five per CU where the runtime
-      // reported six, and the sixth of every CU waited for a slot: -6 %), the occupancy query rounds less
+      // the CU hands out its 160 KB in 1280-B granules (tools/micro/lds_granule.hip: 23 040 B fit seven times and 26 880 B six
+      // times, one byte more does not; 27 104 B per workgroup ran five per CU where the runtime reported six, and the sixth of
+      // every CU waited for a slot: -6 %), the occupancy query rounds less
       const size_t granule = 1280, per_wg = (fa.sharedSizeBytes + fused_lds + granule - 1) / granule * granule;
       fit = std::min<int>(fit, (int)((160 * 1024) / std::max<size_t>(per_wg, granule)));
       if (fit >= want_waves || fused_stack <= 8 || s.dev.n_flat > 0 || std::getenv("LR_STACK_LDS")) break;
