@@ -4,5 +4,5 @@
 WL=$1; VAR=$2; shift 2
 for lib in "$@"; do
   echo "== ${lib:-product}"
-  if [ -n "$lib" ]; then LR_HIP_LIB=$PWD/$lib timeout 600 python3 tools/ab_pipelines.py $WL 2 $VAR; else timeout 600 python3 tools/ab_pipelines.py $WL 2 $VAR; fi
+  if [ -n "$lib" ]; then LR_HIP_LIB=$PWD/$lib timeout ${AB_TIMEOUT:-600} python3 tools/ab_pipelines.py $WL 2 $VAR; else timeout ${AB_TIMEOUT:-600} python3 tools/ab_pipelines.py $WL 2 $VAR; fi
 done
