@@ -658,6 +658,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, u
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
+#ifndef LR_INWALK_RESOLVE
+#define LR_INWALK_RESOLVE 1            // resolve a finished connection inside the walk once this many lanes have one (0: only at retire points)
+#endif
 #ifndef LR_RETIRE_EIGHTHS
 #define LR_RETIRE_EIGHTHS 4            // the walk stops for a retire point when this many eighths of the wave's rays are still under way
 #endif
@@ -755,14 +758,33 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     // ================= walk until at most half of the wave's rays are still under way =================
     const int live_n = __builtin_popcountll(hm);
     const int thresh = live_n * LR_RETIRE_EIGHTHS / 8;
-    const bool conn = NEE && c.has_sh;
 #ifdef LR_DIAG
     tq = __builtin_amdgcn_s_memtime(); dg.walks += 1; dg.walk_lanes += (unsigned)__builtin_popcountll(__ballot(go));
-    do { ptrav_burst<NEE>(sc, tr, ls, conn, stk_n, go, &dg); } while (__builtin_popcountll(__ballot(go)) > thresh);
-    dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq;
-#else
-    do { ptrav_burst<NEE>(sc, tr, ls, conn, stk_n, go); } while (__builtin_popcountll(__ballot(go)) > thresh);
 #endif
+    do {
+#ifdef LR_DIAG
+      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, stk_n, go, &dg);
+#else
+      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, stk_n, go);
+#endif
+#if LR_INWALK_RESOLVE
+      if constexpr (NEE) {
+        // connections whose walk is over do not wait for the retire point once LR_INWALK_RESOLVE of them have gathered: they are
+        // resolved here and their lanes walk on with the continuation ray, so a retire point is about vertices
+        const bool dc = live && !go && c.has_sh;
+        if (__builtin_popcountll(__ballot(dc)) >= LR_INWALK_RESOLVE) {
+          if (dc) {
+            V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), v3(ls.sh_d.v), v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
+            ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+            c.has_sh = false;
+            ptrav_begin(tr, v3(ls.ray_d.v));
+            go = true;
+          }
+        }
+      }
+#endif
+    } while (__builtin_popcountll(__ballot(go)) > thresh);
+    LR_DIAG_ONLY(dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq;)
   }
 #ifdef LR_DIAG
   dg.cyc_total = __builtin_amdgcn_s_memtime() - tq0;
