@@ -316,3 +316,25 @@ def test_ploc_falls_back_on_needle_meshes(dev, monkeypatch, capfd):
     err = capfd.readouterr().err
     assert "falling back to the radix tree" in err, err[-600:]
     assert bad == [0, 0] and excused == 0 and hit > 0.3
+
+
+@pytest.mark.gpu
+def test_fused_kernels_get_the_workgroups_per_cu_they_are_sized_for(dev, monkeypatch, capfd):
+    """The fused kernels launch one workgroup per resident slot; a kernel whose LDS creeps over a 1280-B granule boundary loses a
+    workgroup per CU (tools/micro/lds_granule.hip), and the render then waits for the workgroups that did not fit (-6 % when it
+    happened).  lr_render prices the LDS itself and says what fits under LR_DEBUG: 6 for the flat and the pt-direct tree kernels
+    (thin lens included), 7 for the pt tree kernel."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    import re
+    monkeypatch.setenv("LR_DEBUG", "1")
+    for name, want in (("cbox-spheres.toml", 6), ("mesh-box.toml", 7), ("ibl-lens.toml", 6)):
+        desc = load(name, 64, 48)
+        scene = dev.Scene(desc)
+        capfd.readouterr()
+        scene.render(desc.render_params(spp=2, seed=1))
+        err = capfd.readouterr().err
+        m = re.search(r"fused kernel: (\d+) workgroups per CU fit \((\d+) wanted\)", err)
+        assert m, err[-400:]
+        assert int(m.group(1)) >= int(m.group(2)) == want, (name, m.group(0))
+        scene.close()
