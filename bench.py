@@ -67,8 +67,12 @@ CONFIGS = {
     "c5": ("ibl-lens.toml", 2048, 2048, 8192, None, "the reference's scenes/welcome-2018.toml class: thin lens, HDR IBL sky, GGX mesh; pt-direct",
            "Msamples/sec (whole node), welcome-2018-class 2048x2048 8192 spp IBL"),
 }
-# legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp)
-OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 1024))
+# legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp).  Every leg runs at its STATED size; the warm-up
+# frame of a leg is rendered at 1/8 of the spp (it only has to page the code and the scene in: the timed frame is one launch)
+OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 0))
+# LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
+# silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
+PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4")
 
 
 def parse():
@@ -93,6 +97,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier (nccl = RCCL; testing: gloo)")
     ap.add_argument("--same-device", action="store_true", help="testing on a 1-GPU box: every rank renders on GPU 0")
     ap.add_argument("--dump-film", default=None, help="rank 0 saves the last film as .npy (tests)")
+    ap.add_argument("--allow-overrides", action="store_true", help="run although LR_* variables that change the product path are set (they are recorded in env_overrides)")
+    ap.add_argument("--leg-cpu-seconds", type=float, default=5.0, help="target CPU time of each baseline sample of the other_configs legs")
     return ap.parse_args()
 
 
@@ -229,6 +235,9 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
                 "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
                 "counts_scaled_from_spp": scaled_from,
                 "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] * scale / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
+                # `frac` is issue-slot UTILISATION: a wave instruction counts the same with 64 or with 20 active lanes.  This is the
+                # fraction of the chip's VALU lane-slots that did work: frac x active lanes per instruction / 64
+                "lane_weighted_frac": round(ach / peak * (e["SQ_THREAD_CYCLES_VALU"] * scale / valu) / 64.0, 4) if e.get("SQ_THREAD_CYCLES_VALU") else None,
                 "wave_cycles_parked": round(e["SQ_WAIT_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None,
                 "wave_cycles_issue_stalled": round(e["SQ_WAIT_INST_ANY"] / wc, 3) if wc and e.get("SQ_WAIT_INST_ANY") else None,
                 "note": "the kernel keeps path state in registers / LDS and the scene in caches, so HBM is not its roof (measured_hbm_frac); "
@@ -298,20 +307,45 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
     return out
 
 
+def env_overrides():
+    """Every LR_* variable set in this process's environment (name -> value)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("LR_")}
+
+
+def setup_block(desc, scene, load_s, create_s):
+    """What the reference lumps into `elapse` beside the render (main.rs:139-144) and prints as `bvh construction`
+    (description.rs:67-73), timed separately: scene file + assets -> description, host SAH build, upload."""
+    st = scene.stats()
+    info = desc.bvh_info()
+    return {
+        "scene_load_s": round(load_s, 4),                        # host.Description(): TOML + OBJ/MTL/HDR parse, instancing, host SAH build
+        "host_bvh_build_s": round(info["seconds"], 4),           # of which bvh.rs:69-127 (description.rs:67-73 prints this)
+        "bvh_nodes": info["nodes"], "bvh_max_depth": info["max_depth"],
+        "scene_create_s": round(create_s, 4),                    # lr_scene_create wall time (first call on a device includes context creation)
+        "upload_ms": round(float(st.upload_ms), 3),              # of which host -> HBM copies + device-side table builds
+        "device_bvh_build_ms": round(float(st.bvh_build_ms), 3),  # 0 = the host tree was uploaded (default)
+    }
+
+
 def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_override, args, flags):
     """One short single-GPU leg of another BASELINE config, after the headline's timed region: same lr_render path,
     HIP-event launch times, its own roofline block."""
     scene_file, W, H, stated_spp, integ, what, metric = CONFIGS[cfg]
     spp = spp_override or stated_spp
+    t_l = time.perf_counter()
     desc = host.Description(os.path.join(ROOT, "scenes", scene_file))
+    load_s = time.perf_counter() - t_l
     desc.set_resolution(W, H)
     integ_eff = desc.renderer.integrator if integ is None else integ
+    t_c = time.perf_counter()
     scene = device.Scene(desc, device=0)
+    create_s = time.perf_counter() - t_c
+    setup = setup_block(desc, scene, load_s, create_s)
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, 0, 1)
     canvas = np.zeros((H, W, 3), dtype=np.float32)
     import torch
     for i in range(warmup):
-        scene.render(desc.render_params(spp=spp, seed=1000 + i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)
+        scene.render(desc.render_params(spp=max(1, spp // 8), seed=1000 + i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)
     acc = new_acc(abi)
     torch.cuda.synchronize(0)
     t0 = time.perf_counter()
@@ -330,8 +364,11 @@ def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_overri
                                + ("" if spp == stated_spp else f" [{spp} of the stated {stated_spp} spp: samples are i.i.d., the rate does not depend on spp]"),
                    "baseline_config": cfg, "width": W, "height": H, "spp": spp, "stated_spp": stated_spp, "integrator": integ_name},
     }
+    leg["setup"] = setup
     leg.update(roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, 0, flags))
     scene.close()
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_baseline(desc, W, H, integ, args.leg_cpu_seconds)
     return leg
 
 
@@ -342,6 +379,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    overrides = env_overrides()
+    blocking = [k for k in overrides if k in PRODUCT_ENV]
+    if blocking and not args.allow_overrides:
+        raise SystemExit(f"bench.py: {', '.join(blocking)} set in the environment: these change what the library runs, so the number would not be "
+                         "the product's. Unset them, or pass --allow-overrides (they are then recorded in the line's env_overrides).")
 
     import torch
     from lumillyrender_amd import abi, device, host, multigpu
@@ -385,10 +428,15 @@ def main():
     dev_index = local_rank if world > 1 else 0
 
     spp = base_spp * (world if args.scaling == "weak" else 1)
+    t_l = time.perf_counter()
     desc = host.Description(os.path.join(ROOT, "scenes", scene_file))
+    load_s = time.perf_counter() - t_l
     desc.set_resolution(W, H)
     integ_eff = desc.renderer.integrator if integ is None else integ
+    t_c = time.perf_counter()
     scene = device.Scene(desc, device=dev_index)            # scene resident in HBM from here on
+    create_s = time.perf_counter() - t_c
+    setup = setup_block(desc, scene, load_s, create_s)
     tiles, n_tiles = multigpu.shard_tiles(W, H, args.tile, rank, world)
     flags = (0 if args.no_profile else abi.LR_FLAG_PROFILE) | (abi.LR_FLAG_STREAMING if args.streaming else 0) | (abi.LR_FLAG_RESIDENT if args.resident else 0)
     shared_film = multigpu.SharedFilm(W, H, args.tile, dist, dst=0, group=host_group)   # one film in /dev/shm for the ranks of this node
@@ -423,6 +471,7 @@ def main():
     my_pixels = sum(tiles[i].w * tiles[i].h for i in range(n_tiles))
     assert acc["samples"] == my_pixels * spp * args.steps, f"device finished {acc['samples']} samples, expected {my_pixels * spp * args.steps}"
     rank_ms = [acc["render_ms"] / max(args.steps, 1)]
+    rank_setup = [setup]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -430,6 +479,9 @@ def main():
         all_ms = [None] * world
         dist.all_gather_object(all_ms, rank_ms[0])
         rank_ms = all_ms
+        all_setup = [None] * world
+        dist.all_gather_object(all_setup, setup)
+        rank_setup = all_setup
 
     total_samples = float(W) * H * spp * args.steps
     value = total_samples / elapsed / 1e6
@@ -452,6 +504,11 @@ def main():
             },
             "rank_render_ms": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
             "barrier": barrier_kind,
+            # setup costs, NOT part of `value` (the scene is resident before the timed region): rank 0's in full, every rank's upload beside it
+            "setup": setup,
+            "rank_upload_ms": [round(x["upload_ms"], 3) for x in rank_setup],
+            "rank_host_bvh_build_s": [x["host_bvh_build_s"] for x in rank_setup],
+            "env_overrides": overrides,
         }
         if world == 1:
             out.update(roofline_blocks(abi, args.config, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, args.slots, flags))

@@ -46,6 +46,10 @@ int lr_selftest_emitter_pick(LrScene* scene, int n, const float* xi, int32_t* k_
 /* Sky::radiance (sky.rs:13-21 uniform, :57-78 IBL nearest texel) for n unit directions: rgb_out[3*i..]. */
 int lr_selftest_sky(LrScene* scene, int n, const float* dirs, float* rgb_out);
 
+/* How the scene's IBL map is stored in HBM: 4 = RGBE words (every texel of the caller's map is a Radiance value
+ * c * 2^(e - 136) and re-encodes exactly; decoded on the fly to the same f32 bits), 16 = float4, 0 = no map. */
+int lr_selftest_sky_texel_bytes(LrScene* scene);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,10 @@
 //             {color.rgb, type} {emission.rgb, weight} {param0..2, -}    = the primitive's material, denormalised
 //   emit    3 x float4 per emitter (objects.rs:19-24, instance order):
 //             {p0|c .xyz, type} {p1.xyz | r, pdf} {p2.xyz, cumulative area}
-//   texels  float4 per IBL texel (rgb, -)
+//   texels  float4 per IBL texel (rgb, -); or, when every texel of the map is a Radiance RGBE value (c * 2^(e - 136), the
+//           `image` crate's decode, sky.rs:45-48) -- true of any map that was loaded from an .hdr file -- the RGBE word itself,
+//           4 B per texel, decoded on the fly to the SAME f32 bits (texels_rgbe; lr_scene_create re-encodes, checks every texel
+//           and the device decode of the whole map, and keeps float4 when one fails): 75 MB -> 19 MB for a 3072 x 1536 map
 //
 // Path state (SoA, one entry per resident path slot; every slot always carries a live path because
 // a finished path regenerates the next sample in place):
@@ -63,6 +66,7 @@ struct DevScene {
   const float4* shade;
   const float4* emit;
   const float4* texels;
+  const uint32_t* texels_rgbe;         // non-null: the map as RGBE words r | g << 8 | b << 16 | e << 24 (e >= 10: every value normal or zero), texels unused
   const uint8_t* prim_qid;             // per primitive id: shade queue (= material type)
   int   n_flat;                        // > 0: test all n_flat primitives with scalar loads instead of walking the tree
   // traversal stack of one lane: entries [0, stack_lds) in LDS (entry e of thread t at [e * 256 + t]), deeper ones --

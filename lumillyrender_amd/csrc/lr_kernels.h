@@ -506,6 +506,22 @@ LR_DEV float checker(float u, float v) {                               // lamber
 // a decision), so their divisions and the square root are the 1-ulp hardware forms (see rcp_r): 15 IEEE sequences of ~10
 // instructions each per GGX vertex otherwise.  The half vector and the sampled direction (material_sample) stay exact.
 LR_DEV float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
+// The half vector of a BRDF *evaluation* (ggx.rs:75) feeds the Fresnel term and the distribution only -- the value of the BRDF,
+// never a direction or a decision -- so v_rsq_f32 and three multiplies could replace the IEEE square root and three IEEE divisions
+// (~40 instructions per evaluation).  MEASURED AND NOT KEPT (round 4): +1.5 % on config 5, +2.0 % on config 3, but ggx.rs:34-39's
+// D = a^2 / (pi ((a^2 - 1)(m.n)^2 + 1)^2) cancels catastrophically at the peak of a smooth lobe (roughness 0.2: one ulp of m.n
+// is 1.5e-4 of D), and the BRDF row's film moved to 1.10e-4 from the oracle -- over the 1e-4 bar.  The exact form stays.
+#ifndef LR_FAST_EVAL_HALF
+#define LR_FAST_EVAL_HALF 0
+#endif
+LR_DEV V3 normalize_r(V3 a) {
+#if LR_FAST_EVAL_HALF
+  const float r = __builtin_amdgcn_rsqf(sqr_norm(a));
+  return v3(a.x * r, a.y * r, a.z * r);
+#else
+  return normalize(a);
+#endif
+}
 LR_DEV float ggx_g(float alpha, V3 v, V3 n) {                          // ggx.rs:27-32
   float a2 = alpha * alpha;
   float c = dot(v, n);
@@ -563,7 +579,7 @@ LR_DEV V3 material_brdf(const Mat& m, V3 out_, V3 in_, V3 n, V3 pos, const V3* l
   } else if (MT == LR_MAT_GGX) {                                       // ggx.rs:71-85
     V3 on = orienting_normal(out_, n);
     if (dot(in_, on) <= 0.0f) return v3(0, 0, 0);
-    V3 h = normalize(in_ + out_);
+    V3 h = normalize_r(in_ + out_);
     float alpha = m.m2.x * m.m2.x;
     float f = ggx_fresnel(m.m2.y, in_, h);
     float g = ggx_g(alpha, in_, on) * ggx_g(alpha, out_, on);
@@ -764,9 +780,20 @@ LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
   uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates
   return (y * width + x) % all;
 }
+// one texel of the map.  RGBE words decode as the `image` crate does (c * 2^(e - 136), sky.rs:45-48): the scale is a power of two
+// built from e (lr_scene_create guarantees e >= 10, so it is a normal float) and c < 256, so the product is exact -- the same
+// f32 bits the float4 map would have held, from a quarter of the bytes
+LR_DEV float4 sky_texel(const DevScene& sc, uint64_t i) {
+  if (sc.texels_rgbe) {                                                  // (wave-uniform)
+    const uint32_t w = sc.texels_rgbe[i];
+    const float scale = __uint_as_float(((w >> 24) - 9u) << 23);
+    return make_float4((float)(w & 0xffu) * scale, (float)((w >> 8) & 0xffu) * scale, (float)((w >> 16) & 0xffu) * scale, 0.0f);
+  }
+  return sc.texels[i];
+}
 LR_DEV V3 sky_radiance(const DevScene& sc, V3 dir) {
   if (sc.sky_type == LR_SKY_UNIFORM) return v3(sc.sky_color[0], sc.sky_color[1], sc.sky_color[2]);   // sky.rs:17-21
-  return v3(sc.texels[sky_texel_index(sc, dir)]);
+  return v3(sky_texel(sc, sky_texel_index(sc, dir)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1466,7 +1493,7 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
           in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
           key = (int)__float_as_uint(in.m0.w);                      // {color.rgb, type bits}: the record names its own class
         } else if (ibl) {
-          in.sh = sc.texels[sky_texel_index(sc, v3(in.rd))];        // same round trip as the records of the hit lanes
+          in.sh = sky_texel(sc, sky_texel_index(sc, v3(in.rd)));        // same round trip as the records of the hit lanes
         }
       }
       VertexOut v; v.finished = false; v.has_shadow = false; v.L = v3(0, 0, 0); v.g_term = 1.0f; v.pixel = 0; v.sample = 0; v.sky_fetch = false;
@@ -1966,6 +1993,16 @@ __global__ void k_selftest_sky(DevScene sc, const float* dirs, float* rgb, int n
   if (i >= n) return;
   V3 c = sky_radiance(sc, v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]));
   rgb[3 * (size_t)i] = c.x; rgb[3 * (size_t)i + 1] = c.y; rgb[3 * (size_t)i + 2] = c.z;
+}
+// lr_scene_create: checksum of the DECODED map (every texel through sky_texel), compared with the same sum over the caller's floats
+__global__ void k_sky_checksum(DevScene sc, uint64_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float4 t = sky_texel(sc, i);
+    acc += ((unsigned long long)__float_as_uint(t.x) + 3ull * __float_as_uint(t.y) + 5ull * __float_as_uint(t.z)) * (2ull * i + 1ull);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, acc);
 }
 __global__ void k_selftest_emitter_pick(DevScene sc, const float* xi, int* k_out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -78,6 +78,7 @@ struct LrScene {
   int n_cus = 0;
   // scene blob
   DevBuf<float4> nodes, prims, flat, shade, emit, texels;
+  DevBuf<uint32_t> texels_rgbe;        // the IBL map as RGBE words when every texel re-encodes exactly (lr_device.h)
   DevBuf<uint8_t> prim_qid;
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
@@ -367,11 +368,48 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   std::vector<float4> texels;
+  std::vector<uint32_t> texels_rgbe;
+  unsigned long long sky_sum = 0;                                    // checksum of the caller's floats (k_sky_checksum's formula)
+  size_t n_texels = 0;
   if (d.sky.type == LR_SKY_IBL) {
     if (d.sky.height <= 0 || !d.sky.texels) fail(LR_EINVAL, "IBL sky without texels");
-    size_t n = (size_t)d.sky.height * (size_t)d.sky.height * 2;
-    texels.resize(n);
-    for (size_t i = 0; i < n; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
+    const size_t n = n_texels = (size_t)d.sky.height * (size_t)d.sky.height * 2;
+    // A map that came out of an .hdr file holds Radiance RGBE values, c * 2^(e - 136) per channel with one e per texel (the `image`
+    // crate's decode behind sky.rs:45-48).  Re-encode every texel and keep 4 B instead of 16 B where the decode gives back the
+    // caller's bits; one texel that does not (a procedural float map, a negative or denormal value) keeps the whole map as float4.
+    bool rgbe_ok = !(std::getenv("LR_SKY_FLOAT4") && std::atoi(std::getenv("LR_SKY_FLOAT4")) == 1);
+    texels_rgbe.resize(rgbe_ok ? n : 0);
+    for (size_t i = 0; i < n; ++i) {
+      const float c[3] = {d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2]};
+      uint32_t bits[3]; std::memcpy(bits, c, sizeof(bits));
+      sky_sum += ((unsigned long long)bits[0] + 3ull * bits[1] + 5ull * bits[2]) * (2ull * i + 1ull);
+      if (!rgbe_ok) continue;
+      const float m = std::max(c[0], std::max(c[1], c[2]));
+      uint32_t word = 10u << 24;                                      // (0, 0, 0): any exponent decodes to zero; 10 keeps the scale a normal float
+      if ((bits[0] | bits[1] | bits[2]) != 0u) {
+        int k = 0;
+        if (!(m > 0.0f) || !std::isfinite(m)) { rgbe_ok = false; continue; }
+        (void)std::frexp(m, &k);                                       // m = f * 2^k, f in [0.5, 1): the largest mantissa lands in [128, 256)
+        const int e = k + 128;
+        if (e < 10 || e > 255) { rgbe_ok = false; continue; }
+        uint32_t q[3]; bool exact = true;
+        for (int a = 0; a < 3; ++a) {
+          const float scaled = std::ldexp(c[a], 136 - e);
+          if (!(scaled >= 0.0f && scaled <= 255.0f) || scaled != std::floor(scaled)) { exact = false; break; }
+          q[a] = (uint32_t)scaled;
+          const float back = (float)q[a] * std::ldexp(1.0f, e - 136);
+          if (std::memcmp(&back, &c[a], 4) != 0) { exact = false; break; }   // (also rejects -0.0)
+        }
+        if (!exact) { rgbe_ok = false; continue; }
+        word = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)e << 24);
+      }
+      texels_rgbe[i] = word;
+    }
+    if (!rgbe_ok) {
+      texels_rgbe.clear();
+      texels.resize(n);
+      for (size_t i = 0; i < n; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
+    }
   } else if (d.sky.type != LR_SKY_UNIFORM) fail(LR_EINVAL, "unknown sky type");
 
   {
@@ -432,6 +470,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
   s.shade.upload(shade, s.stream);
   s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
+  if (!texels_rgbe.empty()) s.texels_rgbe.upload(texels_rgbe, s.stream);
   s.prim_qid.upload(qid, s.stream);
   HIP_OK(hipStreamSynchronize(s.stream));
 
@@ -439,6 +478,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   std::memset(&v, 0, sizeof(v));
   v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.emit = s.emit.p;
   v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
+  v.texels_rgbe = texels_rgbe.empty() ? nullptr : s.texels_rgbe.p;
   v.n_flat = (np > 0 && np <= kFlatMax) ? np : 0;
   v.n_emitters = (int)emitters.size(); v.emission_area = emission_area;
   v.sky_type = d.sky.type; v.sky_color[0] = d.sky.color[0]; v.sky_color[1] = d.sky.color[1]; v.sky_color[2] = d.sky.color[2];
@@ -471,6 +511,27 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       float ext = hi[a] - lo[a];
       v.key_lo[a] = np > 0 ? lo[a] : 0.0f;
       v.key_scale[a] = (np > 0 && ext > 0.0f && ext < 3.0e38f) ? 4.0f / ext : 0.0f;
+    }
+  }
+  if (v.texels_rgbe) {
+    // the DEVICE's decode of the whole RGBE map against the caller's floats (one position-weighted checksum over the f32 bits):
+    // whatever the float mode of the kernels, the map the renders read is the map that was handed in -- or it is stored as float4
+    DevBuf<unsigned long long> sum; sum.ensure(1);
+    HIP_OK(hipMemsetAsync(sum.p, 0, sizeof(unsigned long long), s.stream));
+    hipLaunchKernelGGL(k_sky_checksum, dim3(1024), dim3(256), 0, s.stream, s.dev, (uint64_t)n_texels, sum.p);
+    HIP_OK(hipGetLastError());
+    unsigned long long got = 0;
+    HIP_OK(hipMemcpyAsync(&got, sum.p, sizeof(got), hipMemcpyDeviceToHost, s.stream));
+    HIP_OK(hipStreamSynchronize(s.stream));
+    if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] IBL map: %zu texels as RGBE words (%.1f MB instead of %.1f MB), device decode checksum %s\n",
+                                              n_texels, n_texels * 4e-6, n_texels * 16e-6, got == sky_sum ? "matches" : "DIFFERS -> float4");
+    if (got != sky_sum) {
+      texels.resize(n_texels);
+      for (size_t i = 0; i < n_texels; ++i) texels[i] = make_float4(d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2], 0.0f);
+      s.texels.upload(texels, s.stream);
+      HIP_OK(hipStreamSynchronize(s.stream));
+      s.texels_rgbe.release();
+      v.texels = s.texels.p; v.texels_rgbe = nullptr;
     }
   }
 }
@@ -986,7 +1047,7 @@ int lr_scene_destroy(LrScene* s) {
   if (!s) return LR_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->prim_qid.release();
+  s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->texels_rgbe.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
   s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
   s->stats_dev.release(); s->film.release(); s->packed.release(); s->sort_key.release(); s->order.release();
@@ -1151,6 +1212,10 @@ int lr_selftest_sky(LrScene* s, int n, const float* dirs, float* rgb_out) {
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(rgb_out, dc.p, (size_t)n * 12, hipMemcpyDeviceToHost));
   })
+}
+int lr_selftest_sky_texel_bytes(LrScene* s) {
+  if (!s) return LR_EINVAL;
+  return s->dev.sky_type != LR_SKY_IBL ? 0 : (s->dev.texels_rgbe ? 4 : 16);
 }
 int lr_selftest_emitter_pick(LrScene* s, int n, const float* xi, int32_t* k_out) {
   LR_TRY({

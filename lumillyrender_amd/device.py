@@ -47,6 +47,7 @@ def lib():
     l.lr_selftest_brute.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
     l.lr_selftest_emitter_pick.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int32)]
     l.lr_selftest_sky.argtypes = [vp, C.c_int, fp, fp]
+    l.lr_selftest_sky_texel_bytes.argtypes = [vp]
     if hasattr(l, "lr_selftest_rcp"):                      # diagnostics entry point; older builds (tools/sweep.sh) lack it
         l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
@@ -179,6 +180,10 @@ class Scene:
         out = np.empty_like(d)
         _check(lib().lr_selftest_sky(self._h, d.shape[0], _fptr(d), _fptr(out)))
         return out
+
+    def sky_texel_bytes(self):
+        """How the IBL map is stored on the device: 4 (RGBE words, exact decode), 16 (float4) or 0 (no map)."""
+        return _check(lib().lr_selftest_sky_texel_bytes(self._h))
 
     def emitter_pick(self, xi):
         """objects.rs:37-51 on the device: emitter index chosen for each uniform draw."""
