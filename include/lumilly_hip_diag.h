@@ -46,6 +46,19 @@ int lr_selftest_emitter_pick(LrScene* scene, int n, const float* xi, int32_t* k_
 /* Sky::radiance (sky.rs:13-21 uniform, :57-78 IBL nearest texel) for n unit directions: rgb_out[3*i..]. */
 int lr_selftest_sky(LrScene* scene, int n, const float* dirs, float* rgb_out);
 
+/* material/{lambert,phong,blinn_phong,ggx,ideal_refraction}.rs for n inputs of one material, through the per-lane dispatch the
+ * render kernels use: in13[13*i..] = out_.xyz, normal.xyz, position.xyz, xi[3], fly distance;
+ * out10[10*i..] = sample() -> in_.xyz, pdf; brdf(out_, in_, normal, position).rgb; coef(out_, normal, fly distance).rgb. */
+int lr_selftest_material(int device, const LrMaterial* material, int n, const float* in13, float* out10);
+
+/* Camera::sample (camera.rs:64-115 pinhole, :411-476 thin lens, :168-188 omnidirectional) of the scene's camera:
+ * xy[2*i..] = pixel, xi4[4*i..] = the four draws; out8[8*i..] = ray origin.xyz, direction.xyz, geometry term, 0. */
+int lr_selftest_camera(LrScene* scene, int n, const int32_t* xy, const float* xi4, float* out8);
+
+/* Objects::sample_emission in full (objects.rs:37-51 + triangle.rs:140-149 / sphere.rs:79-84): xi4[4*i..] = (-, pick, u, v);
+ * out4[4*i..] = sampled point.xyz, pdf. */
+int lr_selftest_emission_sample(LrScene* scene, int n, const float* xi4, float* out4);
+
 /* How the scene's IBL map is stored in HBM: 4 = RGBE words (every texel of the caller's map is a Radiance value
  * c * 2^(e - 136) and re-encodes exactly; decoded on the fly to the same f32 bits), 16 = float4, 0 = no map. */
 int lr_selftest_sky_texel_bytes(LrScene* scene);

@@ -767,18 +767,32 @@ LR_DEV void camera_sample(const DevCamera& c, int x, int y, const Draw4& d, V3* 
 // sky  (sky.rs)
 // ------------------------------------------------------------------------------------------
 // IBL: the texel a direction looks up (sky.rs:57-78)
+// maps taller than 32768 rows (2^31 texels and up): sky.rs:72-77 in 64 bits, kept out of line -- it would otherwise size the registers of every caller
+__attribute__((noinline)) LR_DEV uint64_t sky_index_wide(uint32_t width, uint32_t height, float fx, float fy) {
+  uint64_t all = (uint64_t)width * height;
+  uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates
+  return (y * width + x) % all;
+}
 LR_DEV uint64_t sky_texel_index(const DevScene& sc, V3 dir) {
   float theta = det_acos(dir.y);
   float phi = det_atan2(dir.z, dir.x);
   float uu = (phi + kPi + sc.sky_lon) / (2.0f * kPi);
-  float u = uu >= 0.0f ? det_fmod_pos(uu, 1.0f) : -det_fmod_pos(-uu, 1.0f);
+  float ru = det_fmod1_pos(__builtin_fabsf(uu));                       // Rust `%`: the remainder keeps the dividend's sign
+  float u = uu >= 0.0f ? ru : -ru;
   float vv = theta / kPi;
-  float v = vv >= 0.0f ? det_fmod_pos(vv, 1.0f) : -det_fmod_pos(-vv, 1.0f);
+  float rv = det_fmod1_pos(__builtin_fabsf(vv));
+  float v = vv >= 0.0f ? rv : -rv;
   uint32_t height = (uint32_t)fresh_s(sc.sky_h), width = height * 2u;
-  uint64_t all = (uint64_t)width * height;
   float fx = __builtin_floorf((float)width * u), fy = __builtin_floorf((float)height * v);
-  uint64_t x = fx > 0.0f ? (uint64_t)fx : 0, y = fy > 0.0f ? (uint64_t)fy : 0;   // `as usize` saturates
-  return (y * width + x) % all;
+  if (height <= 32768u) {
+    // |u|, |v| < 1, so x <= width and y <= height: the index stays below 2 * width * height and `% all` is one conditional
+    // subtraction in 32 bits (a 64-bit remainder is a ~200-instruction routine; `as usize` saturates: negative / NaN -> 0)
+    const uint32_t all = width * height;
+    const uint32_t x = fx > 0.0f ? (uint32_t)fx : 0u, y = fy > 0.0f ? (uint32_t)fy : 0u;
+    const uint32_t i = y * width + x;
+    return i >= all ? i - all : i;
+  }
+  return sky_index_wide(width, height, fx, fy);
 }
 // one texel of the map.  RGBE words decode as the `image` crate does (c * 2^(e - 136), sky.rs:45-48): the scale is a power of two
 // built from e (lr_scene_create guarantees e >= 10, so it is a normal float) and c < 256, so the product is exact -- the same
@@ -2003,6 +2017,41 @@ __global__ void k_sky_checksum(DevScene sc, uint64_t n, unsigned long long* out)
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, acc);
+}
+// material/*.rs on the device for n inputs of ONE material: in13[13*i..] = out_.xyz, n.xyz, pos.xyz, xi.xyz, fly distance;
+// out10[10*i..] = sampled in_.xyz, pdf, brdf(out_, in_).rgb, coef.rgb -- the per-lane dispatch the fused kernels run (material_*_dyn<31>)
+__global__ void k_selftest_material(float4 m0, float4 m1, float4 m2, const float* in13, float* out10, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* a = in13 + 13 * (size_t)i;
+  Mat m; m.m0 = m0; m.m1 = m1; m.m2 = m2;
+  const int mt = (int)__float_as_uint(m0.w);
+  V3 out_ = v3(a[0], a[1], a[2]), nrm = v3(a[3], a[4], a[5]), pos = v3(a[6], a[7], a[8]);
+  V3 in_ = v3(0, 0, 0); float pdf = 0.0f;
+  material_sample_dyn<31u>(mt, m, out_, nrm, a + 9, &in_, &pdf);
+  V3 f = material_brdf_dyn<31u>(mt, m, out_, in_, nrm, pos);
+  V3 c = material_coef_dyn<31u>(mt, m, out_, nrm, a[12]);
+  float* o = out10 + 10 * (size_t)i;
+  o[0] = in_.x; o[1] = in_.y; o[2] = in_.z; o[3] = pdf; o[4] = f.x; o[5] = f.y; o[6] = f.z; o[7] = c.x; o[8] = c.y; o[9] = c.z;
+}
+// camera.rs sample() of the scene's camera: xy[2*i..] = pixel, xi4 = the four draws; out8[8*i..] = origin.xyz, direction.xyz, geometry term, 0
+__global__ void k_selftest_camera(DevScene sc, const int* xy, const float* xi4, float* out8, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Draw4 d; for (int k = 0; k < 4; ++k) d.v[k] = xi4[4 * (size_t)i + k];
+  V3 o, dir; float g;
+  camera_sample(sc.cam, xy[2 * (size_t)i], xy[2 * (size_t)i + 1], d, &o, &dir, &g);
+  float* q = out8 + 8 * (size_t)i;
+  q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = dir.x; q[4] = dir.y; q[5] = dir.z; q[6] = g; q[7] = 0.0f;
+}
+// Objects::sample_emission (objects.rs:37-51, triangle.rs:140-149, sphere.rs:79-84): xi4 = (-, pick, u, v); out4 = point.xyz, pdf
+__global__ void k_selftest_emission_sample(DevScene sc, DevState st, const float* xi4, float* out4, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Draw4 d; for (int k = 0; k < 4; ++k) d.v[k] = xi4[4 * (size_t)i + k];
+  V3 p; float pdf;
+  sample_emission(sc, st, d, &p, &pdf);
+  out4[4 * (size_t)i] = p.x; out4[4 * (size_t)i + 1] = p.y; out4[4 * (size_t)i + 2] = p.z; out4[4 * (size_t)i + 3] = pdf;
 }
 __global__ void k_selftest_emitter_pick(DevScene sc, const float* xi, int* k_out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

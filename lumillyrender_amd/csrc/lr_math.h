@@ -62,50 +62,51 @@ LR_DEV void det_sincos(float xx, float* s_out, float* c_out) {
   *c_out = cneg ? -c : c;
 }
 
+// The four functions below are written WITHOUT divergent branches: a wave executes every branch some lane takes, and the original
+// case analysis (three ranges of atan with two different divisions, three ranges of acos each with its own inlined asin) made the IBL
+// lookup of a miss -- which runs at ~15 of 64 lanes -- walk all of them.  Each lane still evaluates exactly the operations of its own
+// case, on the same operands and in the same order (the case only SELECTS operands), so the results are the same bits as the branching
+// forms the oracle keeps (tests: device == oracle bit for bit on sweeps around every case boundary, test_math_spec_*).
 LR_DEV float det_atan(float xx) {
   const float PIO2F = 1.5707963267948966192f, PIO4F = 0.7853981633974483096f;
-  float x = __builtin_fabsf(xx), y;
-  if (x > 2.414213562373095f) { y = PIO2F; x = -(1.0f / x); }
-  else if (x > 0.4142135623730950f) { y = PIO4F; x = (x - 1.0f) / (x + 1.0f); }
-  else y = 0.0f;
+  float x = __builtin_fabsf(xx);
+  const bool big = x > 2.414213562373095f, mid = !big && x > 0.4142135623730950f;
+  const float y0 = big ? PIO2F : (mid ? PIO4F : 0.0f);
+  // big: -(1 / x) == (-1) / x;  mid: (x - 1) / (x + 1);  else x == x / 1  (one IEEE division instead of two under branches)
+  const float num = big ? -1.0f : (mid ? x - 1.0f : x), den = big ? x : (mid ? x + 1.0f : 1.0f);
+  x = num / den;
   float z = x * x;
   float p = (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
-  y = y + p;
+  float y = y0 + p;
   return xx < 0.0f ? -y : y;
 }
 LR_DEV float det_atan2(float y, float x) {
   const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
-  if (x != x || y != y) return __builtin_nanf("");
-  int code = 0;
-  if (x < 0.0f) code = 2;
-  if (y < 0.0f) code |= 1;
-  if (x == 0.0f) {
-    if (code & 1) return -PIO2F;
-    if (y == 0.0f) return 0.0f;
-    return PIO2F;
-  }
-  if (y == 0.0f) return (code & 2) ? PIF : 0.0f;
-  float w = (code == 2) ? PIF : (code == 3 ? -PIF : 0.0f);
-  return w + det_atan(y / x);
+  const bool xneg = x < 0.0f, yneg = y < 0.0f;
+  const float w = (xneg && !yneg) ? PIF : ((xneg && yneg) ? -PIF : 0.0f);
+  float r = w + det_atan(y / x);
+  r = y == 0.0f ? (xneg ? PIF : 0.0f) : r;
+  r = x == 0.0f ? (yneg ? -PIO2F : (y == 0.0f ? 0.0f : PIO2F)) : r;
+  return (x != x || y != y) ? __builtin_nanf("") : r;
 }
-LR_DEV float det_asin(float xx) {
-  const float PIO2F = 1.5707963267948966192f;
-  float a = __builtin_fabsf(xx);
-  if (a > 1.0f || a != a) return __builtin_nanf("");
-  if (a < 1.0e-4f) return xx;
-  float x, z; bool flag;
-  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = __builtin_sqrtf(z); flag = true; }
-  else { x = a; z = x * x; flag = false; }
-  z = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z + 7.4953002686E-2f) * z + 1.6666752422E-1f) * z * x + x;
-  if (flag) { z = z + z; z = PIO2F - z; }
-  return xx < 0.0f ? -z : z;
+// asin for |t| <= 0.5 (Cephes asinf below its square-root range, including the tiny-argument shortcut)
+LR_DEV float det_asin_half(float t) {
+  float a = __builtin_fabsf(t);
+  float z = a * a;
+  z = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z + 7.4953002686E-2f) * z + 1.6666752422E-1f) * z * a + a;
+  z = a < 1.0e-4f ? a : z;
+  return t < 0.0f ? -z : z;
 }
 LR_DEV float det_acos(float x) {
   const float PIF = 3.141592653589793238f, PIO2F = 1.5707963267948966192f;
-  if (x != x || x < -1.0f || x > 1.0f) return __builtin_nanf("");
-  if (x < -0.5f) return PIF - 2.0f * det_asin(__builtin_sqrtf(0.5f * (1.0f + x)));
-  if (x > 0.5f) return 2.0f * det_asin(__builtin_sqrtf(0.5f * (1.0f - x)));
-  return PIO2F - det_asin(x);
+  // x < -0.5: pi - 2 asin(sqrt(0.5 (1 + x)));  x > 0.5: 2 asin(sqrt(0.5 (1 - x)));  else pi/2 - asin(x).  1 + x == 1 - |x| for a
+  // negative x, the square roots are <= 0.5, so asin never enters its own square-root range: ONE root and ONE polynomial per lane
+  const float ax = __builtin_fabsf(x);
+  const bool outer = ax > 0.5f;
+  const float arg = outer ? __builtin_sqrtf(0.5f * (1.0f - ax)) : x;
+  const float r = det_asin_half(arg);
+  const float res = outer ? (x > 0.5f ? 2.0f * r : PIF - 2.0f * r) : PIO2F - r;
+  return (x != x || ax > 1.0f) ? __builtin_nanf("") : res;
 }
 
 // ---- pow / exp through f64 series (rare: Phong / Blinn-Phong lobes, Beer absorption) --------
@@ -200,6 +201,9 @@ LR_DEV float det_fmod_pos(float x, float k) {
   if (r >= k) r = r - k;
   return r;
 }
+// x mod 1 for x >= 0 (and NaN): the fast path of det_fmod_pos(x, 1) is x - floor(x), exact for every x (>= 2^23: x is an integer and
+// the result 0, as fmodf's; inf: NaN, as fmodf's) -- so the IBL lookup needs neither the range test nor the inlined fmodf behind it
+LR_DEV float det_fmod1_pos(float x) { return x - __builtin_floorf(x); }
 // 1.0f / d, correctly rounded, in five instructions instead of the compiler's ten (v_div_scale x2, v_rcp, 4 fma,
 // mul, v_div_fmas, v_div_fixup): v_rcp_f32 (1 ulp) and two Newton steps with fused residuals.  Bit-equal to the
 // IEEE quotient for every float with 2^-126 <= |d| < 2^126 (biased exponent 1..252) -- checked EXHAUSTIVELY by

@@ -1213,6 +1213,52 @@ int lr_selftest_sky(LrScene* s, int n, const float* dirs, float* rgb_out) {
     HIP_OK(hipMemcpy(rgb_out, dc.p, (size_t)n * 12, hipMemcpyDeviceToHost));
   })
 }
+int lr_selftest_material(int device, const LrMaterial* m, int n, const float* in13, float* out10) {
+  LR_TRY({
+    if (!m || !in13 || !out10 || n < 0) fail(LR_EINVAL, "bad argument");
+    if (m->type < 0 || m->type > LR_MAT_IDEAL_REFRACTION) fail(LR_EINVAL, "unknown material type");
+    HIP_OK(hipSetDevice(device));
+    DevBuf<float> di, dout;
+    di.ensure((size_t)n * 13); dout.ensure((size_t)n * 10);
+    HIP_OK(hipMemcpy(di.p, in13, (size_t)n * 13 * 4, hipMemcpyHostToDevice));
+    // the three material rows exactly as pack_scene lays them out
+    const float w = std::fmax(std::fmax(m->color[0], m->color[1]), m->color[2]);
+    const bool emits = m->type == LR_MAT_LAMBERT;
+    const float4 m0 = make_float4(m->color[0], m->color[1], m->color[2], __builtin_bit_cast(float, (uint32_t)m->type));
+    const float4 m1 = make_float4(emits ? m->emission[0] : 0.0f, emits ? m->emission[1] : 0.0f, emits ? m->emission[2] : 0.0f, w);
+    const float4 m2 = make_float4(m->param[0], m->param[1], m->param[2], 0.0f);
+    if (n > 0) hipLaunchKernelGGL(k_selftest_material, dim3((n + 255) / 256), dim3(256), 0, 0, m0, m1, m2, di.p, dout.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out10, dout.p, (size_t)n * 10 * 4, hipMemcpyDeviceToHost));
+  })
+}
+int lr_selftest_camera(LrScene* s, int n, const int32_t* xy, const float* xi4, float* out8) {
+  LR_TRY({
+    if (!s || !xy || !xi4 || !out8 || n < 0) fail(LR_EINVAL, "bad argument");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<int> dxy; DevBuf<float> dxi, dout;
+    dxy.ensure((size_t)n * 2); dxi.ensure((size_t)n * 4); dout.ensure((size_t)n * 8);
+    HIP_OK(hipMemcpy(dxy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dxi.p, xi4, (size_t)n * 16, hipMemcpyHostToDevice));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_camera, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, dxy.p, dxi.p, dout.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(out8, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  })
+}
+int lr_selftest_emission_sample(LrScene* s, int n, const float* xi4, float* out4) {
+  LR_TRY({
+    if (!s || !xi4 || !out4 || n < 0) fail(LR_EINVAL, "bad argument");
+    if (s->dev.n_emitters <= 0) fail(LR_EINVAL, "scene has no emitters");
+    HIP_OK(hipSetDevice(s->device));
+    DevBuf<float> dxi, dout;
+    dxi.ensure((size_t)n * 4); dout.ensure((size_t)n * 4);
+    HIP_OK(hipMemcpy(dxi.p, xi4, (size_t)n * 16, hipMemcpyHostToDevice));
+    DevState ds; std::memset(&ds, 0, sizeof(ds));
+    if (n > 0) hipLaunchKernelGGL(k_selftest_emission_sample, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, ds, dxi.p, dout.p, n);
+    HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(out4, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  })
+}
 int lr_selftest_sky_texel_bytes(LrScene* s) {
   if (!s) return LR_EINVAL;
   return s->dev.sky_type != LR_SKY_IBL ? 0 : (s->dev.texels_rgbe ? 4 : 16);

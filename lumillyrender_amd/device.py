@@ -47,7 +47,11 @@ def lib():
     l.lr_selftest_brute.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
     l.lr_selftest_emitter_pick.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int32)]
     l.lr_selftest_sky.argtypes = [vp, C.c_int, fp, fp]
-    l.lr_selftest_sky_texel_bytes.argtypes = [vp]
+    if hasattr(l, "lr_selftest_material"):                 # diagnostics entry points of round 4; older builds (tools/ab4.py baselines) lack them
+        l.lr_selftest_sky_texel_bytes.argtypes = [vp]
+        l.lr_selftest_material.argtypes = [C.c_int, C.POINTER(abi.LrMaterial), C.c_int, fp, fp]
+        l.lr_selftest_camera.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), fp, fp]
+        l.lr_selftest_emission_sample.argtypes = [vp, C.c_int, fp, fp]
     if hasattr(l, "lr_selftest_rcp"):                      # diagnostics entry point; older builds (tools/sweep.sh) lack it
         l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
@@ -181,6 +185,21 @@ class Scene:
         _check(lib().lr_selftest_sky(self._h, d.shape[0], _fptr(d), _fptr(out)))
         return out
 
+    def camera_samples(self, xy, xi4):
+        """camera.rs sample() of the scene's camera on the device: (n, 8) = origin, direction, geometry term, 0."""
+        p = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        x = np.ascontiguousarray(xi4, dtype=np.float32).reshape(-1, 4)
+        out = np.empty((p.shape[0], 8), dtype=np.float32)
+        _check(lib().lr_selftest_camera(self._h, p.shape[0], p.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(x), _fptr(out)))
+        return out
+
+    def emission_sample(self, xi4):
+        """objects.rs:37-51 in full on the device: (n, 4) = sampled point, pdf."""
+        x = np.ascontiguousarray(xi4, dtype=np.float32).reshape(-1, 4)
+        out = np.empty_like(x)
+        _check(lib().lr_selftest_emission_sample(self._h, x.shape[0], _fptr(x), _fptr(out)))
+        return out
+
     def sky_texel_bytes(self):
         """How the IBL map is stored on the device: 4 (RGBE words, exact decode), 16 (float4) or 0 (no map)."""
         return _check(lib().lr_selftest_sky_texel_bytes(self._h))
@@ -191,6 +210,15 @@ class Scene:
         k = np.empty(x.size, dtype=np.int32)
         _check(lib().lr_selftest_emitter_pick(self._h, x.size, _fptr(x), k.ctypes.data_as(C.POINTER(C.c_int32))))
         return k
+
+
+def selftest_material(material, in13, device=0):
+    """material/*.rs on the device for one abi.LrMaterial: in13 (n, 13) = out_, normal, position, xi[3], fly distance ->
+    (n, 10) = sampled in_, pdf, brdf(out_, in_), coef."""
+    a = np.ascontiguousarray(in13, dtype=np.float32).reshape(-1, 13)
+    out = np.empty((a.shape[0], 10), dtype=np.float32)
+    _check(lib().lr_selftest_material(device, C.byref(material), a.shape[0], _fptr(a), _fptr(out)))
+    return out
 
 
 def selftest_math(fn, a, b=None, device=0):

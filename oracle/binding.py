@@ -79,6 +79,8 @@ def lib(fast=False):
     l.lr_oracle_sky_batch.restype = None
     l.lr_oracle_emitter_pick.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, C.POINTER(C.c_int32)]
     l.lr_oracle_math_batch.argtypes = [C.c_int, fp, fp, fp, C.c_int]
+    l.lr_oracle_emission_sample.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, fp]
+    l.lr_oracle_aabb_is_intersect.argtypes = [fp, fp, fp]
     l.lr_oracle_sky_radiance.argtypes = [C.POINTER(abi.LrSceneDesc), fp, fp]
     l.lr_oracle_sky_radiance.restype = None
     for n in ("sin", "cos", "acos", "exp"):
@@ -147,6 +149,15 @@ def emitter_pick(description, xi):
 
 
 _MATH_FN = {"sin": 0, "cos": 1, "acos": 2, "atan2": 3, "pow": 4, "exp": 5, "fmod_pos": 6}
+
+
+def emission_sample(description, xi4):
+    """Objects::sample_emission (objects.rs:37-51) for draws (n, 4) = (-, pick, u, v): (n, 4) = point.xyz, pdf."""
+    x = np.ascontiguousarray(xi4, dtype=np.float32).reshape(-1, 4)
+    out = np.empty_like(x)
+    if lib().lr_oracle_emission_sample(description.desc_ptr, x.shape[0], x.ctypes.data_as(fp), out.ctypes.data_as(fp)) != 0:
+        raise RuntimeError("lr_oracle_emission_sample failed")
+    return out
 
 
 def math_batch(name, xs, ys=None):

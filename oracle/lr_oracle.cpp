@@ -1198,6 +1198,23 @@ int lr_oracle_emitter_pick(const LrSceneDesc* desc, int n, const float* xi, int3
   }
   return (int)s.emission.size();
 }
+// Objects::sample_emission in full (objects.rs:37-51 + triangle.rs:140-149 / sphere.rs:79-84): out4[4*i..] = point.xyz, pdf
+int lr_oracle_emission_sample(const LrSceneDesc* desc, int n, const float* xi4, float* out4) {
+  Scene s; if (!build_scene(desc, nullptr, 0, 0.0f, &s)) return LR_EINVAL;
+  if (s.emission.empty()) return LR_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    Draw4 d; std::memcpy(d.v, xi4 + 4 * (size_t)i, 16);
+    V3 val; float pdf; s.sample_emission(d, &val, &pdf);
+    out4[4 * (size_t)i] = val.x; out4[4 * (size_t)i + 1] = val.y; out4[4 * (size_t)i + 2] = val.z; out4[4 * (size_t)i + 3] = pdf;
+  }
+  return 0;
+}
+// AABB::is_intersect (aabb.rs:74-92), literal: box6 = min.xyz, max.xyz
+int lr_oracle_aabb_is_intersect(const float* box6, const float* o, const float* d) {
+  AABB a; a.mn = arr3(box6); a.mx = arr3(box6 + 3);
+  Ray r; r.origin = arr3(o); r.direction = arr3(d);
+  return aabb_is_intersect(a, r, 0.0f) ? 1 : 0;
+}
 void lr_oracle_sky_radiance(const LrSceneDesc* desc, const float* dir, float* rgb) {
   Scene s; if (!build_scene(desc, nullptr, 0, 0.0f, &s)) { rgb[0] = rgb[1] = rgb[2] = 0; return; }
   Ray r; r.origin = v3(0, 0, 0); r.direction = arr3(dir);

@@ -272,20 +272,7 @@ def test_row_stride_and_ragged_tiles(dev):
 
 # ---- committed golden crops, larger scenes, remaining cameras / materials ------------------------------
 
-def test_golden_fixtures(dev):
-    """tests/golden/*.npy (written by tests/golden/make_golden.py with the oracle, pinned on CPU by
-    tests/test_oracle_properties.py): the HIP path must reproduce them without the oracle present."""
-    import os
-    from tests.test_oracle_properties import GOLDEN, GOLDEN_CASES, golden_name
-    for case in GOLDEN_CASES:
-        name, w, h, spp, integ, seed = case
-        desc = load(name, w, h)
-        scene = dev.Scene(desc)
-        img = scene.render(desc.render_params(spp=spp, seed=seed, integrator=integ))
-        ref = np.load(os.path.join(GOLDEN, golden_name(case)))
-        assert linf(img, ref) < TOL, case
-        scene.close()
-
+# (test_golden_fixtures moved to tests/test_gpu_parity_r4.py: film crops AND per-function vectors, consumed without the oracle)
 
 def _generated_assets():
     import os
