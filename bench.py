@@ -324,6 +324,8 @@ def setup_block(desc, scene, load_s, create_s):
         "scene_create_s": round(create_s, 4),                    # lr_scene_create wall time (first call on a device includes context creation)
         "upload_ms": round(float(st.upload_ms), 3),              # of which host -> HBM copies + device-side table builds
         "device_bvh_build_ms": round(float(st.bvh_build_ms), 3),  # 0 = the host tree was uploaded (default)
+        # the 4-wide tree on the device; nodes_without_distance_culling = what the sliver exemption (a heuristic) gives up
+        "tree": scene.tree_info() if hasattr(scene, "tree_info") else None,
     }
 
 

@@ -146,14 +146,16 @@ typedef struct LrRenderParams {
   int32_t  depth;                    /* forced-continue depth, default 5                     */
   int32_t  depth_limit;              /* default 64                                           */
   int32_t  no_direct_emitter;        /* bool                                                 */
-  int32_t  path_slots;               /* 0 = library default; resident path-state slots       */
+  int32_t  path_slots;               /* 0 = library default; path-state slots (paths in flight).  The fused and the resident
+                                        pipeline treat it as an UPPER bound: they cannot use more than one path per lane of
+                                        the waves a GPU holds */
   int32_t  flags;                    /* LR_FLAG_*                                            */
 } LrRenderParams;
 
 #define LR_FLAG_PROFILE 1            /* bracket kernel launches with HIP events (lr_get_stats) */
 #define LR_FLAG_COUNT   2            /* count segments / shadow rays / node visits / prim tests */
 #define LR_FLAG_STREAMING 4          /* force the multi-kernel streaming pipeline (state in HBM)      */
-#define LR_FLAG_RESIDENT  8          /* force the single-launch resident pipeline (state in LDS) if it fits */
+#define LR_FLAG_RESIDENT  8          /* force the single-launch resident pipeline (state in LDS) if it fits; if it does not, the default choice runs */
 #define LR_FLAG_FUSED     16         /* force the fused pipeline: one persistent launch, every lane carries its path in registers */
 
 typedef struct LrTile { int32_t x0, y0, w, h; } LrTile;

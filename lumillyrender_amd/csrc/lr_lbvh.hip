@@ -579,8 +579,13 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
     LB_OK(hipMemcpyAsync(ctr, hctr, sizeof(hctr), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(kB), 0, st, vals2, boxes, n, cb[0], cr[0]);
     int m_host = n, cur = 0, iters = 0;
+    bool stalled = false;                                          // no cluster found a partner in a whole batch (or the iteration budget ran out)
     while (m_host > 1) {
-      if (iters > 4096) { err = "PLOC did not converge"; return LR_EDEVICE; }
+      // A batch without a single merge cannot happen while union areas are finite and below the 3.0e38 `best` sentinel; it does
+      // for coordinates of finite but absurd extent (> ~1e19: the area overflows).  The radix tree below builds such a scene
+      // -- its splits are by key, not by area -- so PLOC gives up instead of failing the scene.
+      if (iters > 4096) { stalled = true; break; }
+      const int m_before = m_host;
       const int g = (m_host + kB - 1) / kB;                       // m only shrinks: the last known count bounds the grid
       for (int k = 0; k < 4; ++k, ++iters) {
         int* m_cur = ctr + (iters & 1);
@@ -595,7 +600,11 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
       LB_OK(hipMemcpyAsync(&m_host, ctr + (iters & 1), sizeof(int), hipMemcpyDeviceToHost, st));
       LB_OK(hipStreamSynchronize(st));
       if (m_host < 1) { err = "PLOC lost its clusters"; return LR_EDEVICE; }
+      if (m_host == m_before) { stalled = true; break; }
     }
+    if (stalled) {
+      if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] ploc: no merge after %d iterations with %d clusters left, falling back to the radix tree\n", iters, m_host);
+    } else {
     const int n_nodes = n - 1;
     hipLaunchKernelGGL(k_ploc_leaf_pos, dim3(grid), dim3(kB), 0, st, nd, n, leaf_pos);
     hipLaunchKernelGGL(k_ploc_emit_nodes, dim3(grid), dim3(kB), 0, st, nd, leaf_pos, n_nodes, d_nodes);
@@ -617,6 +626,7 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
       return LR_OK;
     }
     if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] ploc: tree too deep (%d), falling back to the radix tree\n", h);
+    }
   }
   LB_OK(hipMemsetAsync(flags, 0, (size_t)n * sizeof(int), st));
   LB_OK(hipMemsetAsync(height, 0, (size_t)n * sizeof(int), st));

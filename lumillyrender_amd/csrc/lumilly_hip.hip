@@ -83,6 +83,7 @@ struct LrScene {
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
   int stack_depth = 2;
+  int tree_info[4] = {0, 0, 0, 0};     // 4-wide nodes, nodes without distance culling (a sliver triangle below them), sliver triangles, stack need
   double bvh_build_ms = 0.0;           // device LBVH build time (0 when the host supplied the tree)
   int film_w = 0, film_h = 0;
   int n_prims = 0;
@@ -441,11 +442,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     w4.build(0, &need);
     if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
     s.stack_depth = need + 1;
-    if (std::getenv("LR_DEBUG")) {
+    {
       size_t n_sliver = 0, n_nocull = 0;
       for (int i = 0; i < np; ++i) n_sliver += sliver[i];
       for (size_t k = 0; k < wide.size() / kNodeRows; ++k) n_nocull += __builtin_bit_cast(uint32_t, wide[k * kNodeRows + 2].z) != 0u;
-      std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d; %zu sliver triangles, %zu nodes without distance culling\n",
+      s.tree_info[0] = (int)(wide.size() / kNodeRows); s.tree_info[1] = (int)n_nocull; s.tree_info[2] = (int)n_sliver; s.tree_info[3] = need;
+      if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d; %zu sliver triangles, %zu nodes without distance culling\n",
                    nodes.size() / 4, wide.size() / kNodeRows, kNodeRows * 16, need, n_sliver, n_nocull);
     }
     s.nodes.upload(wide, s.stream);
@@ -643,7 +645,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     if (s.dev.n_flat > 0 && !count && (forced || __builtin_popcount(present_mask) == 1)) fused = true;
     if (s.dev.n_flat == 0 && !count) fused = true;                       // tree scenes: k_path_tree (+56...68 % over the streaming pipeline)
     if (pe && (std::strcmp(pe, "resident") == 0 || std::strcmp(pe, "streaming") == 0)) fused = false;
-    if (rp_in.flags & (LR_FLAG_STREAMING | LR_FLAG_RESIDENT)) fused = false;
+    if (rp_in.flags & LR_FLAG_STREAMING) fused = false;
+    // LR_FLAG_RESIDENT on a scene whose state + stack do not fit the LDS: the request cannot be honoured, and what runs then
+    // is the DEFAULT choice (fused where it applies), not the streaming pipeline (that was up to 68 % slower)
+    if ((rp_in.flags & LR_FLAG_RESIDENT) && resident) fused = false;
     if (fused) resident = false;
   }
   const int resident_per_cu = big_block ? 3 : std::max(1, std::min(LR_RES_WAVES, (int)((160 * 1024) / (resident_lds + 768))));
@@ -692,6 +697,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     if (fit < 1) fail(LR_EUNSUPPORTED, "the fused kernel does not fit a compute unit");
     if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lumilly_hip] fused kernel: %d workgroups per CU fit (%d wanted), %zu B of dynamic LDS\n", fit, want_waves, fused_lds);
     n_slots = (uint32_t)(s.n_cus * std::min(fit, want_waves) * kBlock);
+    // LrRenderParams.path_slots is an UPPER bound here (one path per lane of a resident wave is the most the kernel can use)
+    if (rp_in.path_slots > 0) n_slots = std::min<uint32_t>(n_slots, ((uint32_t)rp_in.path_slots + kBlock - 1) / kBlock * kBlock);
   }
   n_slots = std::max<uint32_t>(kSeg, std::min<uint32_t>(n_slots, ((n_items + kSeg - 1) / kSeg) * kSeg));
   n_slots = (n_slots + kSeg - 1) / kSeg * kSeg;
@@ -1258,6 +1265,11 @@ int lr_selftest_emission_sample(LrScene* s, int n, const float* xi4, float* out4
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(out4, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost));
   })
+}
+int lr_selftest_tree_info(LrScene* s, int32_t* out4) {
+  if (!s || !out4) return LR_EINVAL;
+  for (int k = 0; k < 4; ++k) out4[k] = s->tree_info[k];
+  return LR_OK;
 }
 int lr_selftest_sky_texel_bytes(LrScene* s) {
   if (!s) return LR_EINVAL;

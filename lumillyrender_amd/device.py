@@ -49,6 +49,7 @@ def lib():
     l.lr_selftest_sky.argtypes = [vp, C.c_int, fp, fp]
     if hasattr(l, "lr_selftest_material"):                 # diagnostics entry points of round 4; older builds (tools/ab4.py baselines) lack them
         l.lr_selftest_sky_texel_bytes.argtypes = [vp]
+        l.lr_selftest_tree_info.argtypes = [vp, C.POINTER(C.c_int32)]
         l.lr_selftest_material.argtypes = [C.c_int, C.POINTER(abi.LrMaterial), C.c_int, fp, fp]
         l.lr_selftest_camera.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), fp, fp]
         l.lr_selftest_emission_sample.argtypes = [vp, C.c_int, fp, fp]
@@ -199,6 +200,12 @@ class Scene:
         out = np.empty_like(x)
         _check(lib().lr_selftest_emission_sample(self._h, x.shape[0], _fptr(x), _fptr(out)))
         return out
+
+    def tree_info(self):
+        """{nodes, nodes_without_distance_culling, sliver_triangles, stack_need} of the scene's 4-wide tree."""
+        out = (C.c_int32 * 4)()
+        _check(lib().lr_selftest_tree_info(self._h, out))
+        return {"nodes": out[0], "nodes_without_distance_culling": out[1], "sliver_triangles": out[2], "stack_need": out[3]}
 
     def sky_texel_bytes(self):
         """How the IBL map is stored on the device: 4 (RGBE words, exact decode), 16 (float4) or 0 (no map)."""

@@ -13,7 +13,8 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 ASSET_ROOT = os.path.join(REPO_ROOT, "assets")
-_LIB_PATH = os.path.join(_HERE, "liblumilly_host.so")
+# LR_HOST_LIB=<path>: another build of the SAME library (the sanitizer build of `make -C host asan`, tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("LR_HOST_LIB") or os.path.join(_HERE, "liblumilly_host.so")
 
 
 class LumillyError(RuntimeError):

@@ -67,6 +67,7 @@ class Parser {
   const std::string& t_;
   size_t p_ = 0;
   int line_ = 1;
+  int depth_ = 0;                      // nesting of arrays / inline tables being parsed (parse_value recurses: bounded, an input cannot size the stack)
   ValuePtr root_;
 
   bool eof() const { return p_ >= t_.size(); }
@@ -207,7 +208,11 @@ class Parser {
     t->tab[parts.back()] = v; t->key_order.push_back(parts.back());
   }
 
+  static constexpr int kMaxDepth = 64;
+  struct DepthGuard { int& d; explicit DepthGuard(int& x) : d(x) { ++d; } ~DepthGuard() { --d; } };
   ValuePtr parse_value() {
+    DepthGuard guard(depth_);
+    if (depth_ > kMaxDepth) fail("arrays / inline tables nested deeper than 64");
     auto v = std::make_shared<Value>();
     char c = peek();
     if (c == '"') { v->kind = Value::STRING; v->s = parse_basic_string(); return v; }

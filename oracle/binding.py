@@ -23,8 +23,9 @@ class LrOracleStats(C.Structure):
                 ("prim_tests", C.c_uint64), ("sky_fetches", C.c_uint64), ("seconds", C.c_double)]
 
 
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_FAST_PATH = os.path.join(_HERE, "liboracle_fast.so")      # same source, -O3 -mavx2 (the cpu_baseline build of BASELINE.md section 3)
+# LR_ORACLE_LIB=<path>: the sanitizer build of the checker (`make -C oracle asan`), used for both roles
+_LIB_PATH = os.environ.get("LR_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
+_FAST_PATH = os.environ.get("LR_ORACLE_LIB") or os.path.join(_HERE, "liboracle_fast.so")      # same source, -O3 -mavx2 (the cpu_baseline build of BASELINE.md section 3)
 _libs = {}
 fp = C.POINTER(C.c_float)
 

@@ -229,3 +229,99 @@ def test_grazing_residual_of_distance_culling_is_pinned(dev):
         total += len(rows)
     assert total <= 22 * 7
     print(f"grazing residual: {total} differing rays over {len(fz.RESIDUAL_SEEDS)} seeds x 2 trees x 2e5 rays, worst |cos| {worst_cos:.4f}")
+
+
+# ---- N = 8 rehearsal on one GPU ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("config,w,h", [("c2", 256, 256), ("c4", 480, 344)])
+def test_eight_rank_bench_assembles_the_single_rank_film(tmp_path, config, w, h):
+    """bench.py exactly as the driver launches its 8-GPU scaling run (torch.distributed.run, one process per rank, tiles
+    i % 8), all eight ranks on this box's one GPU: eight scene uploads, eight host BVH builds, eight mappers of one /dev/shm
+    film.  The assembled film equals the 1-rank film bit for bit, the line carries every rank's upload / build time, and no
+    shared-memory segment is left behind (main.rs:61-65,129-132: the reference's channel drain, across processes)."""
+    import glob
+    if config == "c4" and not _generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    before = set(glob.glob("/dev/shm/lumilly_film_*"))
+    common = ["--config", config, "--steps", "1", "--warmup", "0", "--width", str(w), "--height", str(h), "--spp", "16", "--no-cpu-baseline", "--tile", "32"]
+    one = tmp_path / "one.npy"
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-film", str(one)] + common,
+                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    eight = tmp_path / "eight.npy"
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--same-device", "--backend", "gloo",
+                         "--dump-film", str(eight)] + common, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    a, b = np.load(one), np.load(eight)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+    line = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["spp"] == 16
+    assert len(line["rank_upload_ms"]) == 8 and all(x > 0 for x in line["rank_upload_ms"])
+    assert len(line["rank_host_bvh_build_s"]) == 8
+    assert line["rank_render_ms"]["max"] >= line["rank_render_ms"]["min"] > 0
+    assert line["env_overrides"] == {k: v for k, v in env.items() if k.startswith("LR_")}
+    assert set(glob.glob("/dev/shm/lumilly_film_*")) <= before
+
+
+# ---- ADVICE r3 ---------------------------------------------------------------------------------------------------------
+
+def test_device_builder_answers_absurd_extents_with_a_code(dev):
+    """A mesh scaled to ~1e21 units: union-box areas overflow past PLOC's 3.0e38 `best` sentinel, no cluster finds a partner and
+    the builder used to spin through its 4096-iteration budget and report LR_EDEVICE "PLOC did not converge".  It now notices the
+    batch without a merge and hands the primitives to the radix tree (splits by key, not by area); the scene then gets the SAME
+    answer through the device builder as through the host tree -- a statement about the input ("BVH box is not finite" at this
+    size, "scene extent beyond 2^48" a little below), never a device failure.  At 1.3e13 units both builders render."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    from lumillyrender_amd import abi, host
+    for scale, want in (("1.3e19", (abi.LR_EINVAL,)), ("1.3e17", (abi.LR_EUNSUPPORTED,)), ("1.3e13", None)):
+        desc = load("mesh-box.toml", 16, 16, text_edit=lambda t: t.replace("vector = [130, 130, 130]", f"vector = [{scale}, {scale}, {scale}]"))
+        for device_bvh in (False, True):
+            if want is None:
+                sc = dev.Scene(desc, device_bvh=device_bvh)
+                assert sc.tree_info()["nodes"] > 20_000
+                sc.close()
+                continue
+            with pytest.raises(host.LumillyError) as e:
+                dev.Scene(desc, device_bvh=device_bvh)
+            assert e.value.code in want, (scale, device_bvh, e.value)
+
+
+def test_path_slots_bound_and_resident_request_that_does_not_fit(dev):
+    """LrRenderParams.path_slots is an upper bound for the fused pipeline (it used to be ignored), and LR_FLAG_RESIDENT on a scene
+    whose traversal stack does not fit the LDS beside the state now runs the default (fused) pipeline instead of dropping to the
+    streaming one.  Neither changes a film (RNG keys are scheduling-independent)."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    from lumillyrender_amd import abi
+    desc = load("mesh-box.toml", 96, 64)
+    scene = dev.Scene(desc)
+    base = scene.render(desc.render_params(spp=8, seed=9)); st0 = scene.stats()
+    assert st0.pipeline == 2 and st0.path_slots > 4096
+    small = scene.render(desc.render_params(spp=8, seed=9, path_slots=3000)); st1 = scene.stats()
+    assert st1.pipeline == 2 and st1.path_slots == 3072                    # rounded up to whole 256-lane workgroups (and 512-slot segments)
+    assert np.array_equal(base.view(np.uint32), small.view(np.uint32))
+    res = scene.render(desc.render_params(spp=8, seed=9, flags=abi.LR_FLAG_RESIDENT)); st2 = scene.stats()
+    assert st2.pipeline in (1, 2)                                           # resident if it fits this scene's stack, else the default -- never streaming
+    assert np.array_equal(base.view(np.uint32), res.view(np.uint32))
+    scene.close()
+
+
+def test_sliver_exemption_scope_is_tracked(dev):
+    """Triangles with sin(angle at p0) < 1/8 are exempt from distance culling (their Moeller-Trumbore distance is ill-conditioned for
+    every direction) and so is every node above them -- a heuristic threshold, not a bound, so its COST is tracked: the
+    100k-triangle mesh has ~2 300 such triangles and gives up culling in ~3 % of its nodes.  A change that widens the exemption
+    (threshold, propagation) shows up here before it shows up as a slower render."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    scene = dev.Scene(load("mesh-box.toml", 16, 16))
+    info = scene.tree_info()
+    assert 20_000 < info["nodes"] < 40_000 and 10 <= info["stack_need"] <= 60
+    assert 1_000 < info["sliver_triangles"] < 4_000
+    assert 0 < info["nodes_without_distance_culling"] < 0.05 * info["nodes"], info
+    scene.close()
+    flat = dev.Scene(load("cbox-spheres.toml", 16, 16))
+    assert flat.tree_info()["nodes_without_distance_culling"] == 0
+    flat.close()

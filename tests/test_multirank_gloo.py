@@ -91,9 +91,10 @@ def _shared_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_shared_memory_film(tmp_path, world):
-    """bench.py's single-node path: every rank writes its tiles into one film in /dev/shm."""
+    """bench.py's single-node path: every rank writes its tiles into one film in /dev/shm.  world = 8 is the node the
+    driver's scaling run uses (here the 40 x 28 film has six 16-pixel tiles: two of the eight ranks hold NO tile)."""
     out_path = str(tmp_path / "film.npy")
     mp.spawn(_shared_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
     from lumillyrender_amd import host
@@ -104,6 +105,31 @@ def test_shared_memory_film(tmp_path, world):
     for frame in range(2):
         ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4 + frame), threads=2)
         assert np.array_equal(got[frame], ref), frame
+
+
+def _killed_worker(rank, world, port, victim):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lumillyrender_amd import multigpu
+    film = multigpu.SharedFilm(W, H, TILE, dist, dst=0)
+    assert film.shared and not os.path.exists(film.name)
+    film.array[rank % H, 0, 0] = 1.0
+    if rank == victim:
+        os.kill(os.getpid(), 9)                      # a rank dies mid-frame (driver kill, OOM): no close(), no barrier
+    film.collect()
+    film.close()
+    dist.destroy_process_group()
+
+
+def test_a_killed_rank_leaves_nothing_in_dev_shm():
+    """The film's backing file loses its name as soon as every rank has mapped it, so eight ranks of which one is killed
+    between two barriers leave no /dev/shm segment behind (the pages go with the last mapping)."""
+    import glob
+    before = set(glob.glob("/dev/shm/lumilly_film_*"))
+    with pytest.raises(Exception):
+        mp.spawn(_killed_worker, args=(8, _free_port(), 5), nprocs=8, join=True)
+    assert set(glob.glob("/dev/shm/lumilly_film_*")) <= before
 
 
 def _subgroup_worker(rank, world, port, out_path):
