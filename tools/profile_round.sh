@@ -50,7 +50,7 @@ for c in $CFGS; do
     c2) run_cfg c2 cbox-spheres.toml 1024 1024 1024 1024 10 ;;
     c3) run_cfg c3 brdf-row.toml 960 540 4096 4096 10 ;;
     c4) run_cfg c4 mesh-box.toml 1920 1370 2048 2048 3 ;;
-    c5) run_cfg c5 ibl-lens.toml 2048 2048 8192 1024 2 ;;
+    c5) run_cfg c5 ibl-lens.toml 2048 2048 8192 8192 2 ;;
   esac
 done
 du -sh $OUT
