@@ -972,6 +972,7 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
 // ==========================================================================================
 // kernels.  Every kernel walks 512-slot segments (grid-stride over segments, 256 threads).
 // ==========================================================================================
+#ifndef LR_TEMPLATE_KERNELS_ONLY      // (lr_flat.hip instantiates template kernels only: the plain ones live in lumilly_hip.hip)
 __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, DevParams rp) {
   __shared__ PoolLds pl;
   __shared__ uint32_t s_retired;
@@ -988,6 +989,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevScene sc, DevState st, D
     __syncthreads();
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Ray sort (north star: "ray sort/compaction").  Before a workgroup walks the rays of its range (up to 16 K path slots)
@@ -1879,6 +1881,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   stat_flush(gst.stats, s_stat);
 }
 
+#ifndef LR_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(kBlock) k_rank_table(DevScene sc, DevState st) {
   uint32_t stride = gridDim.x * kBlock;
   for (uint32_t rank = blockIdx.x * kBlock + threadIdx.x; rank < st.n_pix; rank += stride) st.rank_pixel[rank] = rank_to_pixel(st, sc.cam, rank);
@@ -2057,5 +2060,7 @@ __global__ void k_selftest_emitter_pick(DevScene sc, const float* xi, int* k_out
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) k_out[i] = emitter_index(sc, sc.emission_area * xi[i]);
 }
+
+#endif  // LR_TEMPLATE_KERNELS_ONLY
 
 }  // namespace lr

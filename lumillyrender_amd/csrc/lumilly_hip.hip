@@ -20,6 +20,20 @@
 #include "lr_path.h"
 #include "lr_lbvh.h"
 
+// the flat-scene kernels are compiled in lr_flat.hip (their own scheduler switch, see there); this unit only launches them
+namespace lr {
+extern template __global__ void k_path_flat<1u, 1>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_path_flat<9u, 1>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_path_flat<31u, 1>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_path_flat<1u, 2>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_path_flat<9u, 2>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_path_flat<31u, 2>(DevScene, DevState, DevParams, const float4*);
+extern template __global__ void k_resident<true, 1u, 512>(DevScene, DevState, DevParams, uint32_t, const float4*);
+extern template __global__ void k_resident<true, 1u, 256>(DevScene, DevState, DevParams, uint32_t, const float4*);
+extern template __global__ void k_resident<true, 31u, 512>(DevScene, DevState, DevParams, uint32_t, const float4*);
+extern template __global__ void k_resident<true, 31u, 256>(DevScene, DevState, DevParams, uint32_t, const float4*);
+}  // namespace lr
+
 using namespace lr;
 
 namespace {
