@@ -44,3 +44,21 @@ def test_committed_profiles_name_their_workload():
     for cfg, (scene, w, h, spp, *_rest) in b.CONFIGS.items():
         want = {"scene": scene, "width": w, "height": h}
         assert b.load_profile("traffic", cfg, want) is not None, cfg          # each BASELINE config has its HBM report
+
+
+def test_bench_refuses_product_changing_environment(tmp_path):
+    """A stale LR_* variable in the shell would silently change what bench.py measures: variables that change
+    the product path are refused before anything touches the GPU, unless --allow-overrides; every LR_* variable is recorded."""
+    import subprocess, sys
+    env = dict(os.environ, LR_PIPELINE="streaming")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "LR_PIPELINE" in (r.stderr + r.stdout) and "--allow-overrides" in (r.stderr + r.stdout)
+    b = _bench()
+    assert {"LR_HIP_LIB", "LR_PIPELINE", "LR_SKY_FLOAT4", "LR_DEVICE_BVH"} <= set(b.PRODUCT_ENV)
+    # every variable the library reads with getenv is either a product switch bench.py knows about or LR_DEBUG (prints only)
+    import re
+    src = ""
+    for f in ("lumillyrender_amd/csrc/lumilly_hip.hip", "lumillyrender_amd/csrc/lr_lbvh.hip", "lumillyrender_amd/device.py", "lumillyrender_amd/host.py"):
+        src += open(os.path.join(ROOT, f)).read()
+    read = set(re.findall(r'getenv\("(LR_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ\.get\("(LR_[A-Z0-9_]+)"\)', src))
+    assert read - set(b.PRODUCT_ENV) <= {"LR_DEBUG"}, read - set(b.PRODUCT_ENV)
