@@ -67,8 +67,8 @@ CONFIGS = {
     "c5": ("ibl-lens.toml", 2048, 2048, 8192, None, "the reference's scenes/welcome-2018.toml class: thin lens, HDR IBL sky, GGX mesh; pt-direct",
            "Msamples/sec (whole node), welcome-2018-class 2048x2048 8192 spp IBL"),
 }
-# legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp).  Every leg runs at its STATED size; the warm-up
-# frame of a leg is rendered at 1/8 of the spp (it only has to page the code and the scene in: the timed frame is one launch)
+# legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp).  Every leg runs at its STATED size, warm-up
+# frame included (the chunk-sum buffer is sized by spp: a shorter warm-up left its allocation -- 17 GB for C5 -- in the timed frame)
 OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 0))
 # LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
 # silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
@@ -347,7 +347,7 @@ def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_overri
     canvas = np.zeros((H, W, 3), dtype=np.float32)
     import torch
     for i in range(warmup):
-        scene.render(desc.render_params(spp=max(1, spp // 8), seed=1000 + i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)
+        scene.render(desc.render_params(spp=spp, seed=1000 + i, integrator=integ, flags=flags), tiles, n_tiles, out=canvas)   # the same frame: buffers sized by spp (chunk sums) are allocated here, not in the timed region
     acc = new_acc(abi)
     torch.cuda.synchronize(0)
     t0 = time.perf_counter()
