@@ -30,6 +30,39 @@
 #ifndef LR_PUSH_BRANCHFREE
 #define LR_PUSH_BRANCHFREE 1
 #endif
+// Wave priorities by phase (s_setprio; round 4).  The SIMD's arbiter picks among its ready waves by priority, then age.  The bulk
+// phase of a kernel -- the node steps of the tree walk, the pass over the primitive rows of a flat scene -- is where a wave spends
+// most of its instructions and, in the tree walk, waits for memory between them; the other phases (leaf tests, the vertex, the
+// finish stage) are shorter ALU-dense stretches after which the wave goes back to requesting rows.  Letting those go first shortens
+// every wave's own serial path without starving anybody (a wave at priority 0 still issues whenever the others wait).
+// Measured, interleaved (gpurun_out/r04s .. r04u; retire / node / leaf): 0/0/0 4031 | 3862 Msamples/s on config 4 | 5;
+// 1/0/0 4049 | 3906;  1/0/1 4110 | 3953 (+2.0 % | +2.4 %);  2/0/1 4099 | 3948;  1/0/2 4117 | 3943;  2/1/0 3986 | 3877;
+// the WALK above the retire point 3949 | 3767.  Flat kernel (finish / trace / vertex): 0/0/0 6019 on configs[1]; 1/0/1 6120 (+1.7 %);
+// 1/0/0 6037; 0/1/0 5855; 2/0/1 6115.  Finer splits measure the same or worse (the four row requests of a node step at their own
+// priority: 4102 | 3941; the finish stage above / below the vertex: 4108 | 3945 and 4074 | 3898; k_resident's phases: within +-0.6 %).
+// The priorities only move instructions in time: films are bit-identical.
+#ifndef LR_PRIO_RETIRE
+#define LR_PRIO_RETIRE 1
+#endif
+#ifndef LR_PRIO_NODE
+#define LR_PRIO_NODE 0
+#endif
+#ifndef LR_PRIO_LEAF
+#define LR_PRIO_LEAF 1
+#endif
+#define LR_PRIO_ANY (LR_PRIO_RETIRE || LR_PRIO_NODE || LR_PRIO_LEAF)
+// the same for k_path_flat's three phases: finish / trace (the pass over the primitive rows) / vertex
+#ifndef LR_PRIO_F_FINISH
+#define LR_PRIO_F_FINISH 1
+#endif
+#ifndef LR_PRIO_F_TRACE
+#define LR_PRIO_F_TRACE 0
+#endif
+#ifndef LR_PRIO_F_VERTEX
+#define LR_PRIO_F_VERTEX 1
+#endif
+#define LR_PRIO_F_ANY (LR_PRIO_F_FINISH || LR_PRIO_F_TRACE || LR_PRIO_F_VERTEX)
+#define LR_SETPRIO(P) asm volatile("s_setprio %0" :: "n"(P) : "memory")
 
 namespace lr {
 
@@ -411,6 +444,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   while (true) {
     // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
+#if LR_PRIO_F_ANY
+    LR_SETPRIO(LR_PRIO_F_FINISH);
+#endif
 #ifdef LR_DIAG
     tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));
     path_finish_spares<D>(sc, st, rp, ls, c, sp, sq, s_stat, &dg);
@@ -425,6 +461,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
     const uint64_t sm = __ballot(live && c.has_sh);
     stat_count(&s_stat[ST_SHADOW], sm);
     // ---- trace: closest hit + the pending connection, one pass over the primitive rows ----
+#if LR_PRIO_F_ANY
+    LR_SETPRIO(LR_PRIO_F_TRACE);
+#endif
     float t = 3.0e38f; int prim = -1;
     LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.walks += 1; dg.walk_lanes += (unsigned)__builtin_popcountll(lm); dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(sm);)
     if (live) {
@@ -444,6 +483,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       }
     }
     // ---- vertex: shade the hit or fold the sky ----
+#if LR_PRIO_F_ANY
+    LR_SETPRIO(LR_PRIO_F_VERTEX);
+#endif
     LR_DIAG_ONLY(dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(live && prim >= 0));)
     path_vertex<MTS>(sc, rp, ls, c, live, t, prim, rec, s_stat);
     LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
@@ -636,6 +678,9 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
 template <bool CONN, class LS>
 LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
   (void)dg;
+#if LR_PRIO_ANY
+  LR_SETPRIO(LR_PRIO_NODE);
+#endif
 #pragma unroll 1
   for (int it = 0; it < (CONN ? LR_BURST_NEE : LR_BURST_PT); ++it) {
     bool nm = go && s.cur >= 0;
@@ -653,6 +698,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, u
     dg->leaf_prims_max += mx; dg->leaf_prims += sm;
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+#if LR_PRIO_ANY
+  if (LR_PRIO_LEAF != LR_PRIO_NODE) LR_SETPRIO(LR_PRIO_LEAF);
 #endif
   if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, ls, conn, stk_n);
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
@@ -733,6 +781,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
     {
+
       LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_finish += 1; dg.l_finish += (unsigned)__builtin_popcountll(__ballot(c.finished || c.fresh));)
 #ifdef LR_DIAG
       path_finish_spares<1>(sc, st, rp, ls, c, sp, sq, s_stat, &dg);
@@ -784,6 +833,9 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
       }
 #endif
     } while (__builtin_popcountll(__ballot(go)) > thresh);
+#if LR_PRIO_ANY
+    LR_SETPRIO(LR_PRIO_RETIRE);
+#endif
     LR_DIAG_ONLY(dg.cyc_walk += __builtin_amdgcn_s_memtime() - tq;)
   }
 #ifdef LR_DIAG

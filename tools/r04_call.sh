@@ -1,9 +1,3 @@
-mkdir -p gpurun_out/r04q
-(time python bench.py) > gpurun_out/r04q/r04_bench_default.json 2> gpurun_out/r04q/bench_default.err
-tail -4 gpurun_out/r04q/bench_default.err
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/r04q/r04_bench_default.json"))
-print(d["value"], d["ms_per_step"], d["roofline"]["lane_weighted_frac"])
-for c,l in d["other_configs"].items(): print(c, l.get("value"), l.get("ms_per_step"), l["roofline"]["frac"], l["roofline"]["lane_weighted_frac"], l["cpu_baseline"]["value"])
-PY
+mkdir -p gpurun_out/r04z; O=gpurun_out/r04z
+timeout 3000 python tools/ab4.py "mesh-box.toml 1920 1370 1024;ibl-lens.toml 2048 2048 512" 3 product build/v_bpt3.so build/v_bpt1.so build/v_bn2.so build/v_bn4.so build/v_re3.so build/v_re5.so > $O/ab.log 2>&1
+cat $O/ab.log
