@@ -1248,6 +1248,8 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
 // direct-light sample (its occlusion test is left to the shadow stage: *has_shadow) and the BSDF sample.
 // Returns true when the path ended here; L / g_term / pixel / sample then describe the finished sample.
 // `st` may point at global memory (streaming pipeline) or at LDS (resident pipeline).
+// which spelling of the generator's multiply-adds a path-state type wants (lr_math.h mad32): the tree kernel's lane state says LO
+template <class ST> struct RngLo { static constexpr bool value = false; };
 struct VertexOut { bool finished, has_shadow; V3 L; float g_term; uint32_t pixel, sample; bool sky_fetch; };
 
 // The rows a vertex reads: the slot's state and (for a hit) the primitive's shading record.  k_shade_all requests them for
@@ -1289,7 +1291,8 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
     const bool emits = !(rp.no_direct_emitter && depth == 0) && !no_emission && dot(out_, nrm) > 0.0f;
     L = L + T * (emits ? emission : v3(0.0f, 0.0f, 0.0f));
     float p = russian_roulette(m.m1.w, depth, rp);                 // scene.rs:161 / :181
-    Draw4 d1 = rng_block(rp.seed, out.pixel, out.sample, 1u + 2u * (uint32_t)depth);
+    constexpr bool rng_lo = NEE == 1 && RngLo<ST>::value;
+    Draw4 d1 = rng_block<rng_lo>(rp.seed, out.pixel, out.sample, 1u + 2u * (uint32_t)depth);
     if (p != 1.0f && d1.v[0] >= p) {                               // scene.rs:162-164 / :182-184
       out.finished = true;
     } else {
@@ -1324,7 +1327,7 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
         }
       }
       // ---- BSDF sample (scene.rs:78-102) ----
-      Draw4 d2r = rng_block(rp.seed, out.pixel, out.sample, 2u + 2u * (uint32_t)depth);
+      Draw4 d2r = rng_block<rng_lo>(rp.seed, out.pixel, out.sample, 2u + 2u * (uint32_t)depth);
       V3 in_; float pdf;
       V3 brdf, coef;
       if constexpr (MT == kMtDyn) {

@@ -237,13 +237,29 @@ LR_DEV float det_powi(float a, int b) {           // compiler-rt __powisf2
 
 // ---- counter-based RNG: pcg4d over (pixel, sample, block, seed) ------------------------------
 struct Draw4 { float v[4]; };
+// a * b + c in 32 bits.  Left to itself the compiler fuses it into v_mad_u64_u32 (a 64-bit sum nobody reads, on a register PAIR);
+// LO = true spells it v_mul_lo_u32 + v_add_u32.  Same integers either way.  Which one is faster is a matter of registers, not of
+// issue slots (round 4, interleaved A/B): the pt-direct tree kernel drops from 13 to 4 spilled VGPRs with LO (48 -> 32 B of
+// scratch; config 5 3950 -> 4017, +1.7 %), the kernels without spills lose 1.3-1.6 % with it (config 4 4109 -> 4057, configs[1]
+// 6110 -> 6015) -- so the caller chooses (shade_vertex_core / path_spare_batch: LO for k_path_tree<., true> only).
+template <bool LO>
+LR_DEV uint32_t mad32(uint32_t a, uint32_t b, uint32_t c) {
+  if constexpr (LO) {
+    uint32_t p;
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+    return p + c;
+  } else {
+    return a * b + c;
+  }
+}
+template <bool LO = false>
 LR_DEV Draw4 rng_block(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t block) {
   uint32_t x = pixel, y = sample, z = block, w = seed;
-  x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u;
-  z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
-  x += y * w; y += z * x; z += x * y; w += y * z;
+  x = mad32<LO>(x, 1664525u, 1013904223u); y = mad32<LO>(y, 1664525u, 1013904223u);
+  z = mad32<LO>(z, 1664525u, 1013904223u); w = mad32<LO>(w, 1664525u, 1013904223u);
+  x = mad32<LO>(y, w, x); y = mad32<LO>(z, x, y); z = mad32<LO>(x, y, z); w = mad32<LO>(y, z, w);
   x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
-  x += y * w; y += z * x; z += x * y; w += y * z;
+  x = mad32<LO>(y, w, x); y = mad32<LO>(z, x, y); z = mad32<LO>(x, y, z); w = mad32<LO>(y, z, w);
   Draw4 d;
   d.v[0] = (float)(x >> 8) * 5.9604644775390625e-08f;
   d.v[1] = (float)(y >> 8) * 5.9604644775390625e-08f;

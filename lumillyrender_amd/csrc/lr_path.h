@@ -75,6 +75,7 @@ struct LaneStateT {
   LaneRow ray_o, ray_d, thr, rad, sh_d, sh_w;
   const LdsRow* emit;                  // the emitter rows, staged in LDS by the kernel (LDS_TABLES: always; otherwise null = read the scene blob)
 };
+template <> struct RngLo<LaneStateT<false>> { static constexpr bool value = true; };   // k_path_tree (with NEE: see shade_vertex_core)
 constexpr int kEmitLds = 8;            // k_path_tree stages up to this many emitters (the scalar-load case of emitter_index)
 template <bool LDS_TABLES>
 LR_DEV float4 emit_row(const LaneStateT<LDS_TABLES>& st, const DevScene& sc, int i) {
