@@ -12,8 +12,9 @@ materials, emitters, sky) is resident in HBM before the timed region starts.
 --config selects the other BASELINE.json configs at their full sizes (single-GPU lines of the 8-GPU configs):
   c3 brdf-row.toml 960x540 4096 spp (GGX row)      c4 mesh-box.toml 1920x1370 2048 spp pt (100k-triangle mesh)
   c5 ibl-lens.toml 2048x2048 8192 spp (thin lens, IBL sky, GGX mesh)
-A default run (c2, one GPU) also renders short legs of c3, c4 and c5 AFTER the headline's timed region and attaches them as
-`other_configs` (c5 at 1024 of its 8192 spp, labelled), so that one driver-run line carries a number for every config.
+A default run (c2, one GPU) also renders legs of c3, c4 and c5 -- each at its STATED size, c5 with all 8192 spp -- AFTER the headline's
+timed region and attaches them as `other_configs`, each with its own `roofline`, `cpu_baseline` and `setup` block, so that one
+driver-run line carries a number for every config (about a minute in all).
 
 Multi-GPU: one process per GPU, pixel tiles of the frame sharded round-robin over ranks, scene replicated, no
 collective on the data path; every rank's lr_render writes its tiles into one film in host shared memory.
@@ -21,7 +22,8 @@ collective on the data path; every rank's lr_render writes its tiles into one fi
 line; --scaling weak renders spp*N per pixel (per-GPU work fixed).
 
 The JSON line also carries
-  roofline       the roof the dominant kernel is under.  The path kernels (k_path_flat / k_path_tree / k_resident) keep
+  roofline       the roof the dominant kernel is under; read `lane_weighted_frac` first (issue-slot utilisation x active lanes per
+                 instruction / 64: what share of the chip's VALU lane-slots did work), `frac` is issue-slot utilisation alone.  The path kernels (k_path_flat / k_path_tree / k_resident) keep
                  the path state in registers or LDS and the scene in caches: they are bound by VALU ISSUE, not by HBM, so
                  `bound` = "valu-issue": VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, transcendentals once
                  more: they hold the port twice as long; from the committed profiles/<round>_pmc_<config>.json of THIS
@@ -34,6 +36,10 @@ The JSON line also carries
                  when it exceeds what HBM could deliver
   cpu_baseline   the CPU oracle (a port of the reference algorithm, oracle/, built -O3 -mavx2) on this box's host cores,
                  on a bounded sample of the same frame
+  setup          scene load, host SAH build seconds (description.rs:67-73's "bvh construction"), lr_scene_create, upload ms, the
+                 4-wide tree's node / no-culling counts -- what main.rs:139-144 lumps into `elapse`; never part of `value`
+  env_overrides  every LR_* variable set in the environment; variables that change the product path (PRODUCT_ENV) are REFUSED
+                 unless --allow-overrides
 """
 import argparse
 import glob
