@@ -16,7 +16,7 @@ A default run (c2, one GPU) also renders legs of c3, c4 and c5 -- each at its ST
 timed region and attaches them as `other_configs`, each with its own `roofline`, `cpu_baseline` and `setup` block, so that one
 driver-run line carries a number for every config (about a minute in all).
 
-Multi-GPU: one process per GPU, pixel tiles of the frame sharded round-robin over ranks, scene replicated, no
+Multi-GPU: one process per GPU, pixel tiles of the frame dealt diagonally over ranks (lr_host_tiles), scene replicated, no
 collective on the data path; every rank's lr_render writes its tiles into one film in host shared memory.
 --scaling strong (default) keeps the frame at the config's spp, so the N-GPU line is the SAME workload as the 1-GPU
 line; --scaling weak renders spp*N per pixel (per-GPU work fixed).
@@ -78,7 +78,8 @@ CONFIGS = {
 OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 0))
 # LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
 # silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
-PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4", "LR_HOST_LIB")
+PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4", "LR_HOST_LIB",
+               "LR_ORACLE_LIB")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
 
 
 def parse():
@@ -91,7 +92,7 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--tile", type=int, default=0, help="tile edge in pixels (0: lr_host_default_tile)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,12 +139,15 @@ def cpu_baseline(desc, W, H, integ, cpu_seconds):
     st2, spp2 = timed(oracle.BVH_ORDERED, 0.05)
     return {
         "value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores,
-        "hardware_threads": os.cpu_count() or cores, "kind": "port", "build": "g++ -O3 -mavx2 -ffp-contract=off (oracle/liboracle_fast.so)",
+        "hardware_threads": os.cpu_count() or cores, "kind": "port", "build": "g++ -O3 -mavx2 -ffp-contract=off (%s)" % os.path.relpath(oracle._FAST_PATH, ROOT),
         "sample": f"{W}x{H} frame at {spp} spp ({st.samples} samples, {st.seconds:.1f} s), oracle in reference-literal BVH mode "
                   "(collect every overlapped leaf, then min), one thread per usable core (affinity and cgroup quota)",
         "optimized": {"value": round(st2.samples / st2.seconds / 1e6, 3), "unit": "Msamples/s",
                       "sample": f"{W}x{H} frame at {spp2} spp ({st2.seconds:.1f} s), ordered early-out traversal of the same tree, row tasks"},
     }
+
+
+LIB_BUILD = [None]          # device.build_id() of the library being timed (set in main)
 
 
 def load_profile(kind, cfg, want):
@@ -239,6 +243,10 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
                 "avg_launch_ms": round(avg_ms, 5), "timed_launches": acc["kernel_timed"][dom],
                 "valu_wave_instr_per_launch": valu, "transcendental_per_launch": trans,
                 "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
+                # the instruction counts are the committed pass's: `profile_current` says whether that pass was taken on the library
+                # that is being timed now (lr_build_info's content hash of csrc/* + flags, tools/build_id.py)
+                "profile_build": gotp[1].get("workload", {}).get("build"), "library_build": LIB_BUILD[0],
+                "profile_current": gotp[1].get("workload", {}).get("build") == LIB_BUILD[0],
                 "counts_scaled_from_spp": scaled_from,
                 "lanes_per_valu_instr": round(e["SQ_THREAD_CYCLES_VALU"] * scale / valu, 1) if e.get("SQ_THREAD_CYCLES_VALU") else None,
                 # `frac` is issue-slot UTILISATION: a wave instruction counts the same with 64 or with 20 active lanes.  This is the
@@ -396,6 +404,9 @@ def main():
 
     import torch
     from lumillyrender_amd import abi, device, host, multigpu
+    if args.tile <= 0:
+        args.tile = host.default_tile()
+    LIB_BUILD[0] = device.build_id()
 
     scene_file, W, H, base_spp, integ, what, metric = CONFIGS[args.config]
     scene_file = args.scene or scene_file
@@ -507,7 +518,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: {scene_file} ({what}) {W}x{H} {spp} spp {integ_name}" + ("" if stated else " [NOT the stated config: overridden on the command line]"),
                 "baseline_config": args.config, "width": W, "height": H, "spp": spp, "integrator": integ_name, "tile": args.tile,
-                "parallelism": f"pixel tiles round-robin over {world} GPU(s), replicated scene, film assembled in host shared memory, no collective on the data path",
+                "parallelism": f"pixel tiles dealt diagonally ((i + k j) mod world) over {world} GPU(s), replicated scene, film assembled in host shared memory, no collective on the data path",
                 "path_slots": acc["path_slots"], "pipeline": PIPELINE_NAMES.get(acc["pipeline"], "?"),
             },
             "rank_render_ms": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},

@@ -80,10 +80,16 @@ int  lr_host_write_hdr_rgbe(const char* path, const uint8_t* rgbe, int width, in
 int  lr_host_to_color(const float* rgb, size_t n, float gamma, uint8_t* out);   /* main.rs:171-173 */
 int  lr_host_load_hdr(const char* path, float** texels_out, int* width_out, int* height_out);
 
-/* Pixel tile queue: cuts the film into tile x tile blocks (row-major) and returns the blocks
- * owned by `rank` of `world` (block i belongs to rank i % world).  Returns the count; writes at
- * most `cap` tiles.  With out == NULL only counts. */
+/* Pixel tile queue (main.rs:65-80: a shared pool of per-pixel jobs): cuts the film into tile x tile blocks and returns the
+ * blocks owned by `rank` of `world`, in row-major order.  Block (i, j) of the tile grid belongs to rank
+ * lr_host_tile_rank(i, j, world) = (i + k * j) mod world with k = lr_host_tile_stride(world) coprime with world: every rank
+ * appears once in any `world` consecutive blocks of a row and of a column, whatever the width of the grid (no stripes).
+ * Returns the count; writes at most `cap` tiles.  With out == NULL only counts. */
+#define LR_HOST_DEFAULT_TILE 16
 int  lr_host_tiles(int width, int height, int tile, int rank, int world, LrTile* out, int cap);
+int  lr_host_tile_rank(int tile_i, int tile_j, int world);
+int  lr_host_tile_stride(int world);
+int  lr_host_default_tile(void);
 
 size_t      lr_host_sizeof(const char* struct_name);   /* ABI self-check for bindings */
 const char* lr_host_last_error(void);

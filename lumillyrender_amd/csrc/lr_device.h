@@ -143,16 +143,26 @@ struct DevState {
   const uint32_t* tile_prefix;         // n_tiles + 1
   uint32_t* rank_pixel;                // n_pix: film pixel of every pixel rank (k_rank_table), one load instead of a search per work item
   int n_tiles;
-  uint32_t n_slots, n_seg, n_pix, n_chunks, chunk_spp, n_items;
+  uint32_t n_slots, n_seg, n_pix, n_chunks, n_items;
+  // a pixel's samples [chunk_start[c], chunk_start[c + 1]) form chunk c (n_chunks + 1 entries; lumilly_hip.hip chunk_schedule: a
+  // function of spp only -- long chunks first, a taper of short ones at the end of the render)
+  const uint32_t* chunk_start;
   // resident pipeline: a workgroup tops its work-item pool up to pool_low by pool_batch items per iteration.  Paths of
   // one workgroup end their chunks in bursts (they all started together), so an open scene at low spp can ask for a
   // hundred items in one iteration, and a lane that finds the pool empty pays a global atomic round trip inside the
   // finish pass: 128 / 256 instead of 24 / 64 tripled such scenes.  Small jobs keep small batches (tail balance).
   uint32_t pool_low, pool_batch;
+  // reservations shrink towards the end of the render: a trip to the dispenser asks for at most (items left) >> pool_shift
+  // (about half a fair share of what is left per wave / workgroup), so the last items are not parked in one pool while other
+  // lanes have retired
+  uint32_t pool_shift;
   uint32_t trace_spb;                  // segments per k_trace workgroup pass: its per-BSDF lists span that many segments
   uint32_t shade_ordered;              // k_shade turns each list back into slot order in LDS before shading (coalesced state rows)
   uint32_t dense_shade;                // k_shade_all shades the slots in place: k_trace writes no lists
   int stack_depth;                     // LDS traversal stack entries per lane
+#ifdef LR_TIMELINE
+  unsigned long long* timeline;        // diagnostic build (make timeline): per wave {entry, dispenser seen dry, exit} in s_memrealtime ticks (100 MHz)
+#endif
 };
 
 }  // namespace lr

@@ -45,6 +45,13 @@ LR_DEV uint32_t lane_id() { const uint32_t m = fresh_s(~0u); return __builtin_am
 // threadIdx.x from the wave's first thread id (a scalar, kept by the caller) -- threadIdx.x itself is an entry value too
 LR_DEV uint32_t tid_of(uint32_t wave_base) { return wave_base + lane_id(); }
 LR_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// make timeline (-DLR_TIMELINE): when every wave of the one-launch kernels entered, first saw the item dispenser dry, and left
+// (lr_render prints the distribution: the ramp and the tail of a render, i.e. its fixed cost per call)
+#ifdef LR_TIMELINE
+#define LR_TL(ST, SLOT) { if (lane_id() == 0) (ST).timeline[3 * ((size_t)blockIdx.x * (blockDim.x >> 6) + (uniform(threadIdx.x) >> 6)) + (SLOT)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define LR_TL(ST, SLOT)
+#endif
 // count `mask`'s lanes into a workgroup statistic (converged wave): one LDS atomic without return, no register kept
 LR_DEV void stat_count(uint32_t* lds_stat, uint64_t mask) {
   if (mask != 0 && lane_id() == 0) atomicAdd(lds_stat, (uint32_t)__builtin_popcountll(mask));
@@ -936,8 +943,7 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
     sum = v3(a) + delta;
     sample += 1;
     uint32_t chunk = item / st.n_pix;
-    uint32_t end = (chunk + 1) * st.chunk_spp;
-    if (end > (uint32_t)rp.spp) end = (uint32_t)rp.spp;
+    uint32_t end = st.chunk_start[chunk + 1];
     if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
   }
   uint32_t k = wave_reserve(&pl->taken, need_item);
@@ -954,7 +960,7 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
     if (!retired) {
       uint32_t rank = item % st.n_pix, chunk = item / st.n_pix;
       pixel = item_pixel(st, sc.cam, rank);
-      sample = chunk * st.chunk_spp;
+      sample = st.chunk_start[chunk];
       sum = v3(0, 0, 0);
     }
   }
@@ -1683,9 +1689,15 @@ LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t b
   if (pl->a0 < need && pl->a1 == 0) {
     uint32_t cur = __hip_atomic_load(st.next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur < st.n_items) {
+      // towards the end of the render a workgroup asks for less (DevState::pool_shift), never less than what it is short of now
+      const uint32_t fair = (st.n_items - cur) >> st.pool_shift, floor_ = need > pl->a0 ? need - pl->a0 : 1u;
+      if (batch > fair) batch = fair > floor_ ? fair : floor_;
       uint32_t nb = atomicAdd(st.next_item, batch);
       if (nb < st.n_items) { pl->r1 = nb; pl->a1 = st.n_items - nb < batch ? st.n_items - nb : batch; }
     }
+#ifdef LR_TIMELINE
+    else { unsigned long long* e = st.timeline + 3 * ((size_t)blockIdx.x * (blockDim.x >> 6)) + 1; if (*e == 0) *e = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (pl->a0 == 0) { pl->r0 = pl->r1; pl->a0 = pl->a1; pl->a1 = 0; }
   }
 }
@@ -1768,6 +1780,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   __syncthreads();
   if (tid == 0) pool_step(st, &pl, st.pool_low, st.pool_batch);     // later top-ups happen in phase 2
   uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0, parity = 0;
+  LR_TL(gst, 0)
 #ifdef LR_STAMP
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #define LR_TICK(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tk[i] += t_now - t_prev; t_prev = t_now; }
@@ -1876,6 +1889,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   // diagnostic build only: lane 0 of every wave adds its cycle shares to the tail of the stats buffer
   if (lane_id() == 0) for (int i = 0; i < 6; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
 #endif
+  LR_TL(gst, 2)
   stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
   stat_accumulate(&s_stat[ST_SHADOW], n_shq);
   stat_accumulate(&s_stat[ST_SAMPLES], n_done);

@@ -241,7 +241,8 @@ struct Draw4 { float v[4]; };
 // LO = true spells it v_mul_lo_u32 + v_add_u32.  Same integers either way.  Which one is faster is a matter of registers, not of
 // issue slots (round 4, interleaved A/B): the pt-direct tree kernel drops from 13 to 4 spilled VGPRs with LO (48 -> 32 B of
 // scratch; config 5 3950 -> 4017, +1.7 %), the kernels without spills lose 1.3-1.6 % with it (config 4 4109 -> 4057, configs[1]
-// 6110 -> 6015) -- so the caller chooses (shade_vertex_core / path_spare_batch: LO for k_path_tree<., true> only).
+// 6110 -> 6015) -- so the caller chooses: shade_vertex_core takes LO for k_path_tree<., true> only (RngLo<LaneStateT<false>>); the camera
+// block of path_spare_batch and every other caller keep the compiler's spelling (rng_block<false>), which is what was measured.
 template <bool LO>
 LR_DEV uint32_t mad32(uint32_t a, uint32_t b, uint32_t c) {
   if constexpr (LO) {

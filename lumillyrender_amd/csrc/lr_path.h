@@ -275,13 +275,20 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
     uint32_t r0 = uniform(sp.pool[0]), a0 = uniform(sp.pool[1]), dry = uniform(sp.pool[2]);
     uint32_t r1 = 0, a1 = 0;
     if (cnt > a0 && !dry) {                                         // one trip to the dispenser per pool_batch items: the wave waits for it
-      const uint32_t ask = st.pool_batch > cnt - a0 ? st.pool_batch : cnt - a0;
+      // ... fewer towards the end of the render: at most (items left when this wave last looked) >> pool_shift, so that the last
+      // items are not parked in one wave's pool while the lanes of other waves retire (the tail of a render is a fixed cost per
+      // call: 1/8 of a frame on each of 8 GPUs pays it in full)
+      const uint32_t n_items = st.n_items, seen = uniform(sp.pool[3]);
+      uint32_t batch = st.pool_batch;
+      const uint32_t fair = (n_items - seen) >> st.pool_shift;
+      if (batch > fair) batch = fair;
+      const uint32_t ask = batch > cnt - a0 ? batch : cnt - a0;
       uint32_t nb = 0;
       if (lane_id() == 0) nb = atomicAdd(st.next_item, ask);
       r1 = uniform(nb);
-      const uint32_t n_items = st.n_items;
       if (r1 < n_items) a1 = n_items - r1 < ask ? n_items - r1 : ask;
-      if (a1 < ask) dry = 1u;
+      if (a1 < ask) { dry = 1u; LR_TL(st, 1) }
+      if (lane_id() == 0) sp.pool[3] = r1 < n_items ? r1 : n_items;
     }
     const uint32_t k = rank_in_mask(nm);
     if (need_item) {
@@ -292,9 +299,8 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
         const uint32_t n_pix = fresh_s(st.n_pix);
         uint32_t chunk = item / n_pix, rank = item - chunk * n_pix;
         pixel = st.rank_pixel[rank];
-        sample = chunk * st.chunk_spp;
-        uint32_t e = sample + st.chunk_spp;
-        sp.end[tid] = e > (uint32_t)rp.spp ? (uint32_t)rp.spp : e;
+        sample = st.chunk_start[chunk];
+        sp.end[tid] = st.chunk_start[chunk + 1];
       }
     }
     // advance the pool by what was handed out (wave-uniform)
@@ -443,6 +449,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
   uint32_t sq = 0;                                                   // the lane's queue of spares (sq_count / sq_head)
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
+  LR_TL(st, 0)
   while (true) {
     // ---- finish: fold, install the spare camera sample; new spares where the wave is short of them ----
 #if LR_PRIO_F_ANY
@@ -499,6 +506,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
     for (int i = 0; i < (int)(sizeof(PathDiag) / 8); ++i) atomicAdd(od + i, v[i]);
   }
 #endif
+  LR_TL(st, 2)
   __syncthreads();
   stat_flush(st.stats, s_stat);
 }
@@ -755,6 +763,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   bool go = false;                                                   // the lane's walk is under way
   uint32_t sq = 0;                                                   // the lane's queue of one spare
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
+  LR_TL(st, 0)
   while (true) {
     // ================= retire point (converged) =================
     // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, the spare count, has_sh, occluded.)
@@ -847,6 +856,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     for (int i = 0; i < (int)(sizeof(PathDiag) / 8); ++i) atomicAdd(od + i, v[i]);
   }
 #endif
+  LR_TL(st, 2)
   __syncthreads();
   stat_flush(st.stats, s_stat);
 }

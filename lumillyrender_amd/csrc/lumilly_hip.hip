@@ -104,13 +104,16 @@ struct LrScene {
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
-  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill;
+  DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill, chunk_start;
   DevBuf<uint16_t> sort_key, order;
   DevBuf<uint4> pool;
   DevBuf<int4> tiles;
   DevBuf<unsigned long long> stats_dev;
   DevBuf<float> film;
   DevBuf<float> packed;                // the rendered tiles' pixels in pixel-rank order (lr_render reads back only these)
+#ifdef LR_TIMELINE
+  DevBuf<unsigned long long> timeline;
+#endif
   uint32_t* pinned = nullptr;         // [0..2], [4..6] retired-slot read-backs (two polls x up to three slot groups), [8..] stats
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
   hipEvent_t t_begin = nullptr, t_end = nullptr;
@@ -552,6 +555,35 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 }
 
+// Work items = (chunk, pixel); a pixel's spp samples are cut into chunks, each folded in order by one lane into a chunk sum, and
+// k_resolve adds a pixel's chunk sums in chunk order (main.rs:92-121 is one flat fold; the difference is a few ulp of radiance).
+// The cut is a function of spp ONLY, so the film does not depend on tiling, slot count, pipeline or GPU count.
+//   body   chunks of L samples: L = 8 ... 16 up to 1024 spp (at most 64 of them), 16 ... 32 beyond (at most 256)
+//   taper  the LAST samples of every pixel in chunks of L/2, L/4, ... 1 (kTaperRepeat of each, twice as many of 1): items are
+//          dispensed chunk-major, so a render ends on single-sample items.  A lane ends the render inside its last item, and with
+//          one chunk length throughout that tail was 2-3 chunk times of the slowest lanes with every other lane idle: 3 ms of a
+//          177-ms frame on configs[1], 7.5 ms of 206 on config 3, 14-18 ms on config 5 -- a FIXED cost per call, paid in full by
+//          each rank of an 8-GPU job that renders 1/8 of the frame (profiles/r05_timeline_before.txt: 12 % / 23 % / 6 % there).
+constexpr uint32_t kTaperRepeat = 8;
+std::vector<uint32_t> chunk_schedule(uint32_t spp) {
+  uint32_t n0 = spp <= 1024 ? std::min<uint32_t>(64, std::max<uint32_t>(1, spp / 8)) : std::min<uint32_t>(256, spp / 16);
+  const uint32_t L = (spp + n0 - 1) / n0;
+  uint32_t level_sum = 0;
+  for (uint32_t l = L / 2; l >= 1; l /= 2) level_sum += l;
+  uint32_t R = kTaperRepeat;
+  if (level_sum == 0) R = 0;
+  else R = std::min<uint32_t>(R, spp / (2 * (level_sum + 1)));            // the taper takes at most half of the samples
+  const uint32_t taper = R * (level_sum + 1), body = spp - taper;
+  std::vector<uint32_t> start;
+  uint32_t at = 0;
+  for (; at + L <= body; at += L) start.push_back(at);
+  if (at < body) { start.push_back(at); at = body; }                      // (a shorter last body chunk)
+  for (uint32_t l = L / 2; l >= 1 && R > 0; l /= 2)
+    for (uint32_t k = 0; k < R * (l == 1 ? 2u : 1u); ++k) { start.push_back(at); at += l; }
+  start.push_back(spp);
+  return start;
+}
+
 int grid_for(const void* kernel, int n_cus, size_t lds, uint32_t work_items) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -623,9 +655,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // chunks: a function of spp ONLY, so the image does not depend on tiling, slot count or GPU count
   // up to 1024 spp: chunks of >= 8 samples, at most 64; beyond: chunks of >= 16 samples, at most 256 -- a slot ends the
   // render inside its last chunk, so the chunk length is the tail of the render (weak scaling raises spp per pixel)
-  uint32_t n_chunks = rp_in.spp <= 1024 ? (uint32_t)std::min(64, std::max(1, rp_in.spp / 8)) : (uint32_t)std::min(256, rp_in.spp / 16);
-  uint32_t chunk_spp = ((uint32_t)rp_in.spp + n_chunks - 1) / n_chunks;
-  n_chunks = ((uint32_t)rp_in.spp + chunk_spp - 1) / chunk_spp;
+  const std::vector<uint32_t> chunks = chunk_schedule((uint32_t)rp_in.spp);
+  const uint32_t n_chunks = (uint32_t)chunks.size() - 1;
+  uint32_t chunk_spp = 1;                                                 // the longest chunk
+  for (uint32_t c = 0; c < n_chunks; ++c) chunk_spp = std::max(chunk_spp, chunks[c + 1] - chunks[c]);
   uint64_t n_items64 = (uint64_t)n_pix * n_chunks;
   if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
   const uint32_t n_items = (uint32_t)n_items64;
@@ -740,7 +773,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     s.film.ensure((size_t)W * H * 3);
     HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
   }
-  s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st);
+  s.tiles.upload(tl, st); s.tile_prefix.upload(prefix, st); s.chunk_start.upload(chunks, st);
   if (!s.pinned) HIP_OK(hipHostMalloc((void**)&s.pinned, (8 + 2 * kStatShards * kStatStride) * sizeof(uint64_t)));
   if (!s.poll_ev[0]) { HIP_OK(hipEventCreate(&s.poll_ev[0])); HIP_OK(hipEventCreate(&s.poll_ev[1])); HIP_OK(hipEventCreate(&s.t_begin)); HIP_OK(hipEventCreate(&s.t_end)); }
   const bool profile = (rp_in.flags & LR_FLAG_PROFILE) != 0;
@@ -760,12 +793,19 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (want_packed) s.packed.ensure((size_t)std::max<uint32_t>(n_pix, 1) * 3);
   ds.stats = s.stats_dev.p; ds.partial = s.partial.p; ds.film = s.film.p; ds.packed = want_packed ? s.packed.p : nullptr;
   ds.tiles = s.tiles.p; ds.tile_prefix = s.tile_prefix.p; ds.n_tiles = (int)tl.size(); ds.rank_pixel = s.rank_pixel.p;
-  ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_spp = chunk_spp; ds.n_items = n_items;
+  ds.n_slots = n_slots; ds.n_seg = n_seg; ds.n_pix = n_pix; ds.n_chunks = n_chunks; ds.chunk_start = s.chunk_start.p; ds.n_items = n_items;
   ds.stack_depth = s.stack_depth;
+#ifdef LR_TIMELINE
+  s.timeline.ensure((size_t)3 * (n_slots / 64 + 8));
+  HIP_OK(hipMemsetAsync(s.timeline.p, 0, (size_t)3 * (n_slots / 64 + 8) * sizeof(unsigned long long), st));
+  ds.timeline = s.timeline.p;
+#endif
   {
     const uint64_t per_block = n_items64 / (4ull * std::max<uint32_t>(1u, n_slots / kRSeg));   // per 256 slots (a 512-slot workgroup refills twice as much: below)
     ds.pool_batch = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(64, per_block));
     ds.pool_low = ds.pool_batch >= 128 ? ds.pool_batch / 2 : 24;
+    ds.pool_shift = 0;
+    while ((1ull << ds.pool_shift) < 2ull * std::max<uint32_t>(1u, n_slots / (uint32_t)RB)) ++ds.pool_shift;   // 2 x the workgroups that draw from the dispenser
   }
   DevParams dp; dp.integrator = rp_in.integrator; dp.spp = rp_in.spp; dp.seed = rp_in.seed; dp.depth = rp_in.depth;
   dp.depth_limit = rp_in.depth_limit; dp.no_direct_emitter = rp_in.no_direct_emitter ? 1 : 0;
@@ -799,6 +839,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
     ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
     ds.pool_low = std::max<uint32_t>(1, ds.pool_batch / 2);
+    ds.pool_shift = 0;
+    while ((1ull << ds.pool_shift) < 2ull * n_waves) ++ds.pool_shift;     // 2 x the waves that draw from the dispenser
     if (s.dev.n_flat == 0) {
       dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
       if (dsc.spill_depth > 0) {
@@ -961,6 +1003,30 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
   HIP_OK(hipMemcpyAsync(hshards, s.stats_dev.p, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+#ifdef LR_TIMELINE
+  if (n_items > 0 && (fused || resident)) {
+    // per wave {entry, dispenser seen dry, exit} in 100-MHz ticks -> the ramp and the tail of the one launch (ms relative to the first entry)
+    const size_t nw = n_slots / 64;
+    std::vector<unsigned long long> tl(3 * nw);
+    HIP_OK(hipMemcpy(tl.data(), s.timeline.p, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> en, dr, ex; unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < nw; ++w) if (tl[3 * w] && tl[3 * w] < t0) t0 = tl[3 * w];
+    double busy = 0.0;
+    for (size_t w = 0; w < nw; ++w) {
+      if (!tl[3 * w] || !tl[3 * w + 2]) continue;
+      en.push_back((tl[3 * w] - t0) * 1e-5); ex.push_back((tl[3 * w + 2] - t0) * 1e-5);
+      if (tl[3 * w + 1]) dr.push_back((tl[3 * w + 1] - t0) * 1e-5);
+      busy += (tl[3 * w + 2] - tl[3 * w]) * 1e-5;
+    }
+    std::sort(en.begin(), en.end()); std::sort(dr.begin(), dr.end()); std::sort(ex.begin(), ex.end());
+    auto q = [](const std::vector<double>& v, double f) { return v.empty() ? -1.0 : v[std::min(v.size() - 1, (size_t)(f * (v.size() - 1) + 0.5))]; };
+    const double span = ex.empty() ? 0.0 : ex.back();
+    std::fprintf(stderr, "[LR_TIMELINE] {\"waves\": %zu, \"span_ms\": %.3f, \"entry_ms\": [%.3f, %.3f, %.3f, %.3f], \"dry_ms\": [%.3f, %.3f, %.3f], "
+                 "\"exit_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f, %.3f, %.3f], \"wave_time_over_span\": %.4f, \"quantiles\": \"entry 0.5 0.9 0.99 1 | dry 0 0.5 1 | exit 0 0.01 0.1 0.5 0.9 0.99 1\"}\n",
+                 en.size(), span, q(en, 0.5), q(en, 0.9), q(en, 0.99), q(en, 1.0), q(dr, 0.0), q(dr, 0.5), q(dr, 1.0),
+                 q(ex, 0.0), q(ex, 0.01), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 0.99), q(ex, 1.0), en.empty() ? 0.0 : busy / (en.size() * span));
+  }
+#endif
 #ifdef LR_STAMP
   {
     unsigned long long tk[8];
@@ -1031,7 +1097,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
 extern "C" {
 
 const char* lr_last_error(void) { return g_err.c_str(); }
-const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2"; }
+#ifndef LR_BUILD_ID
+#define LR_BUILD_ID "unknown"          /* diagnostic variants (make diag / stamp / timeline) are not built through the id header */
+#endif
+const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2 build=" LR_BUILD_ID; }
 
 int lr_device_count(void) {
   int n = 0;
@@ -1070,7 +1139,7 @@ int lr_scene_destroy(LrScene* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->texels_rgbe.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release();
+  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release(); s->chunk_start.release();
   s->stats_dev.release(); s->film.release(); s->packed.release(); s->sort_key.release(); s->order.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->host_film) (void)hipHostFree(s->host_film);

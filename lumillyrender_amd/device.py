@@ -59,6 +59,17 @@ def lib():
     return l
 
 
+def build_info():
+    """lr_build_info(): target, float mode, ABI version and the content hash of the sources + flags the library was built from."""
+    return lib().lr_build_info().decode()
+
+
+def build_id():
+    """The `build=` field of lr_build_info (tools/build_id.py): what ties a committed profile to the library that was profiled."""
+    info = build_info()
+    return info.split("build=", 1)[1].split()[0] if "build=" in info else "unknown"
+
+
 def _check(rc):
     if rc < 0:
         raise LumillyError(rc, lib().lr_last_error().decode("utf-8", "replace"))

@@ -56,6 +56,9 @@ def _load():
     lib.lr_host_to_color.argtypes = [fp, C.c_size_t, C.c_float, C.POINTER(C.c_uint8)]
     lib.lr_host_load_hdr.argtypes = [C.c_char_p, C.POINTER(fp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.lr_host_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.LrTile), C.c_int]
+    lib.lr_host_tile_rank.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.lr_host_tile_stride.argtypes = [C.c_int]
+    lib.lr_host_default_tile.argtypes = []
     lib.lr_host_sizeof.argtypes = [C.c_char_p]
     lib.lr_host_sizeof.restype = C.c_size_t
     return lib
@@ -155,8 +158,24 @@ class Description:
         return p
 
 
-def tiles(width, height, tile=64, rank=0, world=1):
-    """Pixel tile queue shard of `rank` (block i of the row-major tile grid goes to rank i % world)."""
+def default_tile():
+    return int(lib().lr_host_default_tile())
+
+
+def tile_rank(i, j, world):
+    return int(lib().lr_host_tile_rank(i, j, world))
+
+
+def tile_split_name():
+    return "tile (i, j) -> rank (i + k j) mod world, k = lr_host_tile_stride(world) (8: %d, 4: %d, 2: %d); default tile %d px" % (
+        lib().lr_host_tile_stride(8), lib().lr_host_tile_stride(4), lib().lr_host_tile_stride(2), default_tile())
+
+
+def tiles(width, height, tile=0, rank=0, world=1):
+    """Pixel tile queue shard of `rank`: block (i, j) of the tile grid goes to rank (i + k j) mod world (lumilly_host.h);
+    tile = 0: the library's default size."""
+    if tile <= 0:
+        tile = default_tile()
     n = _check(lib().lr_host_tiles(width, height, tile, rank, world, None, 0))
     arr = (abi.LrTile * max(n, 1))()
     _check(lib().lr_host_tiles(width, height, tile, rank, world, arr, n))

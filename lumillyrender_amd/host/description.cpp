@@ -3,6 +3,7 @@
 // instance order, OBJ faces become triangles in file order, spheres take the transformed origin
 // and an UNSCALED radius, emission binds to objects by light.object == object.name.
 #include "host_internal.h"
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -333,13 +334,37 @@ int lr_host_load_hdr(const char* path, float** texels_out, int* w_out, int* h_ou
   })
 }
 
+// The reference farms one job per pixel from a shared pool (main.rs:65-80,104,121: whichever worker is free takes the next
+// pixel), balanced by construction.  One process per GPU has no shared pool, so the deal itself must not be able to
+// degenerate: tile (i, j) of the tile grid goes to rank (i + k * j) mod world, k = the stride nearest 0.382 * world that
+// is coprime with world (world 8: k = 3, world 4: k = 1, world 2: checkerboard).  Every rank then appears once in any `world`
+// consecutive tiles of a ROW and of a COLUMN whatever the width of the grid -- `id % world` (round 4) gave rank r whole
+// columns whenever the grid was a multiple of `world` wide (the 16- and 32-tile-wide films of configs 2 and 5: heaviest
+// rank +12 % / +10 %, profiles/r05_strong_rank_before_*.json).
+int lr_host_tile_stride(int world) {
+  if (world <= 2) return 1;
+  int best = 1; double bd = 1e30;
+  for (int k = 1; k < world; ++k) {
+    int a = k, b = world; while (b) { int t = a % b; a = b; b = t; }
+    if (a != 1) continue;
+    const double d = std::fabs((double)k - 0.382 * (double)world);
+    if (d < bd) { bd = d; best = k; }
+  }
+  return best;
+}
+int lr_host_tile_rank(int i, int j, int world) {
+  if (world <= 0 || i < 0 || j < 0) return -1;
+  return (int)(((long long)i + (long long)lr_host_tile_stride(world) * j) % world);
+}
+int lr_host_default_tile(void) { return LR_HOST_DEFAULT_TILE; }
+
 int lr_host_tiles(int width, int height, int tile, int rank, int world, LrTile* out, int cap) {
   if (width <= 0 || height <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world) { set_last_error("bad tiling arguments"); return LR_EINVAL; }
-  int tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile, count = 0;
+  const int tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile, k = lr_host_tile_stride(world);
+  int count = 0;
   for (int j = 0; j < ty; ++j)
     for (int i = 0; i < tx; ++i) {
-      int id = j * tx + i;
-      if (id % world != rank) continue;
+      if ((int)(((long long)i + (long long)k * j) % world) != rank) continue;
       if (out && count < cap) {
         LrTile t; t.x0 = i * tile; t.y0 = j * tile;
         t.w = std::min(tile, width - t.x0); t.h = std::min(tile, height - t.y0);

@@ -60,9 +60,9 @@ int main(int argc, char** argv) {
     LrScene* sc = nullptr;
     int rcode = lr_scene_create(g, desc, &sc);
     if (rcode == LR_OK) {
-      int n = lr_host_tiles(W, H, 64, g, gpus, nullptr, 0);
+      int n = lr_host_tiles(W, H, lr_host_default_tile(), g, gpus, nullptr, 0);
       std::vector<LrTile> tiles((size_t)std::max(n, 1));
-      lr_host_tiles(W, H, 64, g, gpus, tiles.data(), n);
+      lr_host_tiles(W, H, lr_host_default_tile(), g, gpus, tiles.data(), n);
       rcode = lr_render(sc, &rp, tiles.data(), n, film.data(), (size_t)W * 3);   // disjoint tiles: threads share the film
     }
     if (rcode != LR_OK) errors[(size_t)g] = lr_last_error();

@@ -32,6 +32,18 @@ def films():
         print(path, img.shape, float(np.nanmean(img)))
 
 
+def stated_spp_films():
+    for case in gc.STATED_SPP_CASES:
+        name, edit, w, h, spp, integ, seed, gen = case
+        if gen and not gc.have_generated_assets():
+            print("skipped (generated assets missing):", gc.film_name(case)); continue
+        d = gc.load_scene(name, edit, w, h)
+        img = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.BVH, pad=0.0)
+        path = os.path.join(gc.GOLDEN, gc.film_name(case))
+        np.save(path, img)
+        print(path, img.shape, float(np.nanmean(img)), float(np.nanmax(img)))
+
+
 def functions():
     out = {}
     L = oracle.lib()
@@ -91,4 +103,5 @@ def functions():
 
 if __name__ == "__main__":
     films()
+    stated_spp_films()
     functions()

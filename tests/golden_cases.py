@@ -56,6 +56,19 @@ FILM_CASES = [
 ]
 
 
+# The four GPU configs of BASELINE.json AT THEIR STATED spp on an 8 x 6 film (round 5): main.rs:92-121 folds spp samples per pixel
+# in one pass; the device cuts them into chunks whose schedule changes with spp (lumilly_hip.hip chunk_schedule: body + taper,
+# 16-sample chunks up to 1024 spp, 32-sample chunks beyond) and k_resolve adds up to ~300 chunk sums per pixel -- the branch every
+# stated config takes and no 8-spp crop reaches.  Generated with the oracle's reference-literal tree (bvh.rs:131-141, mode BVH,
+# pad 0; the brute-force definition gives the same bits on these films and takes minutes on the 100k-triangle scenes).
+STATED_SPP_CASES = [
+    ("cbox-spheres.toml", None, 8, 6, 1024, 1, 5, False),       # configs[1]
+    ("brdf-row.toml", None, 8, 6, 4096, 1, 5, False),           # configs[2]
+    ("mesh-box.toml", None, 8, 6, 2048, 0, 5, True),            # configs[3]
+    ("ibl-lens.toml", None, 8, 6, 8192, 1, 5, True),            # configs[4]
+]
+
+
 def film_name(case):
     name, edit, w, h, spp, integ, seed, _ = case
     tag = "" if edit is None else "_" + edit

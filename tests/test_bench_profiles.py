@@ -46,6 +46,23 @@ def test_committed_profiles_name_their_workload():
         assert b.load_profile("traffic", cfg, want) is not None, cfg          # each BASELINE config has its HBM report
 
 
+def _tree_build_id():
+    import subprocess, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_id
+    flags = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "lumillyrender_amd", "csrc"), "print-flags"], capture_output=True, text=True, check=True).stdout.strip()
+    return build_id.build_id(flags)
+
+
+def test_library_build_id_is_the_content_hash_of_the_sources():
+    """lr_build_info() carries sha256(csrc/* + the C-ABI headers)[:16] + '-' + sha256(flags)[:8] (tools/build_id.py, written by the
+    Makefile): the in-tree library is the one the sources in the tree build, and a profile that records this id names its library."""
+    from lumillyrender_amd import device
+    info = device.build_info()
+    assert "gfx950" in info and "build=" in info
+    assert device.build_id() == _tree_build_id(), "liblumilly_hip.so is stale against lumillyrender_amd/csrc (run make -C lumillyrender_amd/csrc)"
+
+
 def test_bench_refuses_product_changing_environment(tmp_path):
     """A stale LR_* variable in the shell would silently change what bench.py measures: variables that change
     the product path are refused before anything touches the GPU, unless --allow-overrides; every LR_* variable is recorded."""
@@ -54,11 +71,12 @@ def test_bench_refuses_product_changing_environment(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "LR_PIPELINE" in (r.stderr + r.stdout) and "--allow-overrides" in (r.stderr + r.stdout)
     b = _bench()
-    assert {"LR_HIP_LIB", "LR_PIPELINE", "LR_SKY_FLOAT4", "LR_DEVICE_BVH"} <= set(b.PRODUCT_ENV)
+    assert {"LR_HIP_LIB", "LR_PIPELINE", "LR_SKY_FLOAT4", "LR_DEVICE_BVH", "LR_ORACLE_LIB"} <= set(b.PRODUCT_ENV)
     # every variable the library reads with getenv is either a product switch bench.py knows about or LR_DEBUG (prints only)
     import re
     src = ""
-    for f in ("lumillyrender_amd/csrc/lumilly_hip.hip", "lumillyrender_amd/csrc/lr_lbvh.hip", "lumillyrender_amd/device.py", "lumillyrender_amd/host.py"):
+    for f in ("lumillyrender_amd/csrc/lumilly_hip.hip", "lumillyrender_amd/csrc/lr_lbvh.hip", "lumillyrender_amd/device.py", "lumillyrender_amd/host.py",
+              "oracle/binding.py"):                                                            # (LR_ORACLE_LIB swaps the library cpu_baseline times)
         src += open(os.path.join(ROOT, f)).read()
     read = set(re.findall(r'getenv\("(LR_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ\.get\("(LR_[A-Z0-9_]+)"\)', src))
     assert read - set(b.PRODUCT_ENV) <= {"LR_DEBUG"}, read - set(b.PRODUCT_ENV)

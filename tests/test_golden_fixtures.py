@@ -32,6 +32,19 @@ def test_oracle_reproduces_the_film_crops(case):
     assert np.isfinite(ref).mean() > 0.99 and float(np.nanmax(ref)) > 0.0
 
 
+@pytest.mark.parametrize("case", gc.STATED_SPP_CASES, ids=[gc.film_name(c).replace(".npy", "") for c in gc.STATED_SPP_CASES])
+def test_oracle_reproduces_the_stated_spp_crops(case):
+    """The BASELINE configs at their stated spp (1024 / 4096 / 2048 / 8192) on an 8 x 6 film, through the reference-literal tree."""
+    name, edit, w, h, spp, integ, seed, gen = case
+    if gen and not gc.have_generated_assets():
+        pytest.skip("generated assets missing (run __graft_entry__.build())")
+    d = gc.load_scene(name, edit, w, h)
+    img, st = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.BVH, pad=0.0, with_stats=True)
+    ref = np.load(os.path.join(gc.GOLDEN, gc.film_name(case)))
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st.samples == w * h * spp and np.isfinite(ref).all() and float(ref.max()) > 0.0
+
+
 def test_aabb_is_intersect_vectors(fn):
     """aabb.rs:74-92, literal (three divisions, early exit): the device replaces it by conservative quantised boxes that only prune,
     so this vector pins the oracle's reference-literal traversal mode only."""

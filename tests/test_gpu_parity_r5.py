@@ -1,0 +1,167 @@
+"""GPU parity, round 5: the BASELINE configs at their STATED spp (the chunk schedule's body + taper and k_resolve's sum of up to
+~300 chunk sums, main.rs:92-121), spp values around every edge of that schedule, the balance of the diagonal tile deal on the
+four stated films, and the per-pixel form of the HDR bar."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, scene_path  # noqa: F401
+from tests import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lumillyrender_amd import device
+    assert device.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return device
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import binding
+    return binding
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _within_bar(img, ref):
+    """L-infinity < 1e-4 per channel on the linear film; a pixel brighter than 1 (HDR films: IBL texels of ~10^3, light sources
+    seen directly) gets 1e-4 of ITS OWN value -- per pixel, not 1e-4 of the film's maximum."""
+    return np.abs(img - ref) < TOL * np.maximum(1.0, np.abs(ref))
+
+
+STATED = [pytest.param(c, id=f"{c[0].replace('.toml', '')}-{c[4]}spp") for c in gc.STATED_SPP_CASES]
+
+
+@pytest.mark.parametrize("case", STATED)
+@pytest.mark.parametrize("film", [(4, 4), (8, 6)], ids=["4x4", "8x6"])
+def test_stated_spp_parity_with_the_oracle(dev, oracle, case, film):
+    """configs[1..4] at their stated 1024 / 4096 / 2048 / 8192 spp, default pipeline, against the oracle's flat fold of the same
+    samples (main.rs:92-121) through the reference-literal tree (bvh.rs:131-141): the 1e-4 bar, identical sample / segment /
+    shadow-ray / sky-fetch counters."""
+    name, edit, _, _, spp, integ, seed, gen = case
+    if gen and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    w, h = film
+    desc = gc.load_scene(name, edit, w, h)
+    p = desc.render_params(spp=spp, seed=seed + 1, integrator=integ)
+    scene = dev.Scene(desc)
+    img = scene.render(p)
+    st = scene.stats()
+    ref, so = oracle.render(desc, p, mode=oracle.BVH, pad=0.0, with_stats=True)
+    assert np.isfinite(ref).all() and np.isfinite(img).all()
+    assert (st.samples, st.segments, st.shadow_rays, st.sky_fetches) == (so.samples, so.segments, so.shadow_rays, so.sky_fetches)
+    assert st.samples == w * h * spp
+    assert _within_bar(img, ref).all(), float(np.max(np.abs(img - ref) / np.maximum(1.0, np.abs(ref))))
+    scene.close()
+
+
+@pytest.mark.parametrize("case", STATED)
+def test_stated_spp_films_are_pipeline_independent(dev, case):
+    """At the stated spp the default pipeline, the streaming pipeline and (flat scenes) the resident and the fused one give the
+    same bits: same chunk schedule, same order of additions into a sample's radiance, same k_resolve."""
+    from lumillyrender_amd import abi
+    name, edit, _, _, spp, integ, seed, gen = case
+    if gen and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    desc = gc.load_scene(name, edit, 4, 4)
+    scene = dev.Scene(desc)
+    films, stats = {}, {}
+    flags = {"default": 0, "streaming": abi.LR_FLAG_STREAMING, "fused": abi.LR_FLAG_FUSED}
+    if name in ("cbox-spheres.toml", "brdf-row.toml"):
+        flags["resident"] = abi.LR_FLAG_RESIDENT
+    for k, f in flags.items():
+        films[k] = scene.render(desc.render_params(spp=spp, seed=seed, integrator=integ, flags=f))
+        s = scene.stats()
+        stats[k] = (s.samples, s.segments, s.shadow_rays, s.sky_fetches, s.pipeline)
+    assert stats["streaming"][4] == 0 and stats["fused"][4] == 2
+    for k in flags:
+        assert np.array_equal(_bits(films[k]), _bits(films["default"])), k
+        assert stats[k][:4] == stats["default"][:4], k
+    scene.close()
+
+
+def test_stated_spp_golden_crops(dev):
+    """tests/golden/*_8x6_<stated spp>spp_*.npy (oracle output, pinned on CPU by tests/test_golden_fixtures.py) through lr_render
+    with no oracle in the process."""
+    ran = 0
+    for case in gc.STATED_SPP_CASES:
+        name, edit, w, h, spp, integ, seed, gen = case
+        if gen and not gc.have_generated_assets():
+            continue
+        desc = gc.load_scene(name, edit, w, h)
+        scene = dev.Scene(desc)
+        img = scene.render(desc.render_params(spp=spp, seed=seed, integrator=integ))
+        ref = np.load(os.path.join(gc.GOLDEN, gc.film_name(case)))
+        assert _within_bar(img, ref).all(), (case, float(np.max(np.abs(img - ref))))
+        assert scene.stats().samples == w * h * spp
+        scene.close(); ran += 1
+    assert ran >= 2
+
+
+def test_hdr_golden_crop_per_pixel_bar(dev):
+    """The thin-lens + IBL crop (film max 64, median 0.5) under the PER-PIXEL bar |img - ref| < 1e-4 max(1, |ref|): round 4 allowed
+    every pixel 1e-4 of the film's maximum (6.4e-3)."""
+    if not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    case = [c for c in gc.FILM_CASES if c[0] == "ibl-lens.toml"][0]
+    name, edit, w, h, spp, integ, seed, _ = case
+    desc = gc.load_scene(name, edit, w, h)
+    scene = dev.Scene(desc)
+    img = scene.render(desc.render_params(spp=spp, seed=seed, integrator=integ))
+    ref = np.load(os.path.join(gc.GOLDEN, gc.film_name(case)))
+    assert float(ref.max()) > 10.0
+    assert _within_bar(img, ref).all(), float(np.max(np.abs(img - ref) / np.maximum(1.0, np.abs(ref))))
+    scene.close()
+
+
+@pytest.mark.parametrize("spp", [1, 7, 15, 16, 17, 31, 32, 33, 63, 64, 100, 129, 257, 1000, 1025, 1040, 2047])
+def test_chunk_schedule_edges(dev, oracle, spp):
+    """The chunk schedule is a function of spp only (body of 8- / 16- / 32-sample chunks + a taper of halving lengths down to
+    single samples, a shorter last body chunk when spp does not divide): every sample exactly once -- counters equal the oracle's,
+    film within the bar -- for spp around every edge of the rule."""
+    desc = gc.load_scene("cbox-spheres.toml", None, 6, 4)
+    p = desc.render_params(spp=spp, seed=11, integrator=1)
+    scene = dev.Scene(desc)
+    img = scene.render(p)
+    st = scene.stats()
+    ref, so = oracle.render(desc, p, with_stats=True)
+    assert st.samples == 6 * 4 * spp
+    assert (st.samples, st.segments, st.shadow_rays) == (so.samples, so.segments, so.shadow_rays)
+    assert _within_bar(img, ref).all()
+    scene.close()
+
+
+@pytest.mark.parametrize("cfg", [("cbox-spheres.toml", 1024, 1024, 1), ("brdf-row.toml", 960, 540, 1), ("mesh-box.toml", 1920, 1370, 0),
+                                 ("ibl-lens.toml", 2048, 2048, 1)], ids=["c2", "c3", "c4", "c5"])
+def test_tile_deal_is_balanced_on_the_stated_films(dev, cfg):
+    """lr_host_tiles at world 8 on the four stated films (4 spp): the heaviest rank's segments + shadow rays are within 3 % of the
+    mean (round 4's `id % world` on 64-px tiles: +12 % / +12 % / +1 % / +5 %), and the eight shares assemble the one-rank film
+    bit for bit."""
+    from lumillyrender_amd import host
+    name, W, H, integ = cfg
+    if name in ("mesh-box.toml", "ibl-lens.toml") and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    desc = gc.load_scene(name, None, W, H)
+    scene = dev.Scene(desc)
+    p = desc.render_params(spp=4, seed=2, integrator=integ)
+    whole = scene.render(p)
+    film = np.full((H, W, 3), -1.0, dtype=np.float32)
+    work = []
+    for r in range(8):
+        tiles, n = host.tiles(W, H, 0, r, 8)
+        scene.render(p, tiles, n, out=film)
+        s = scene.stats()
+        work.append(int(s.segments) + int(s.shadow_rays))
+    assert np.array_equal(_bits(film), _bits(whole))
+    work = np.array(work, dtype=np.float64)
+    assert work.max() / work.mean() <= 1.03, work / work.mean()
+    assert work.min() / work.mean() >= 0.97, work / work.mean()
+    scene.close()

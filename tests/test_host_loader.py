@@ -303,18 +303,49 @@ def test_bvh_standalone_many_triangles():
 
 
 def test_tiles_partition_the_film():
-    W, H, T = 70, 45, 16
-    for world in (1, 2, 3, 8):
-        cover = np.zeros((H, W), dtype=int)
-        for rank in range(world):
-            tiles, n = host.tiles(W, H, T, rank, world)
-            for i in range(n):
-                t = tiles[i]
-                assert t.w > 0 and t.h > 0 and t.x0 + t.w <= W and t.y0 + t.h <= H
-                cover[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] += 1
-        assert np.all(cover == 1)
+    """Disjoint cover for every film / tile / world, including the 16- and 32-tile-wide grids of configs 2 and 5 on which
+    round 4's `id % world` degenerated into column stripes."""
+    cases = [(70, 45, 16), (1024, 1024, 64), (1024, 1024, 32), (2048, 2048, 64), (960, 540, 32), (1920, 1370, 32), (33, 7, 8), (5, 5, 64)]
+    for W, H, T in cases:
+        for world in (1, 2, 3, 4, 5, 8):
+            cover = np.zeros((H, W), dtype=np.int32)
+            pix = []
+            for rank in range(world):
+                tiles, n = host.tiles(W, H, T, rank, world)
+                k = 0
+                for i in range(n):
+                    t = tiles[i]
+                    assert t.w > 0 and t.h > 0 and t.x0 + t.w <= W and t.y0 + t.h <= H
+                    assert t.x0 % T == 0 and t.y0 % T == 0
+                    assert host.tile_rank(t.x0 // T, t.y0 // T, world) == rank
+                    cover[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w] += 1
+                    k += t.w * t.h
+                pix.append(k)
+            assert np.all(cover == 1), (W, H, T, world)
     with pytest.raises(host.LumillyError):
-        host.tiles(W, H, T, 3, 3)
+        host.tiles(70, 45, 16, 3, 3)
+    assert host.default_tile() == 16
+    t0, n0 = host.tiles(64, 64, 0, 0, 1)
+    assert n0 == 16 and t0[0].w == 16
+
+
+def test_tile_deal_cannot_stripe():
+    """Whatever the grid width: any `world` consecutive tiles of a row AND of a column go to `world` different ranks
+    (lumilly_host.h; main.rs:65-80's shared pool is balanced by construction, a static deal must not be able to degenerate)."""
+    for world in (2, 3, 4, 5, 6, 7, 8, 16):
+        k = host.lib().lr_host_tile_stride(world)
+        assert 1 <= k < max(world, 2) and np.gcd(k, world) == 1
+        for tx in (world, 2 * world, 16, 32, 15, 30, 17):
+            grid = np.array([[host.tile_rank(i, j, world) for i in range(tx)] for j in range(3 * world)])
+            for j in range(grid.shape[0]):
+                for i in range(tx - world + 1):
+                    assert len(set(grid[j, i:i + world])) == world
+            for i in range(tx):
+                for j in range(grid.shape[0] - world + 1):
+                    assert len(set(grid[j:j + world, i])) == world
+            if tx >= world:
+                counts = np.bincount(grid.reshape(-1), minlength=world)
+                assert counts.max() - counts.min() <= grid.shape[0]
 
 
 def test_png_output_matches_to_color(tmp_path):

@@ -13,6 +13,7 @@ OUT=$PWD/gpurun_out/$TAG
 PROF=$OUT/profiles
 mkdir -p "$OUT" "$PROF" profiles
 REV=$(cat .git_rev 2>/dev/null || echo unknown)
+BUILD=$(python3 -c "from lumillyrender_amd import device; print(device.build_id())")     # content hash of csrc/* + flags inside the library that is profiled
 export TMPDIR=/tmp
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"
 SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE"
@@ -27,7 +28,7 @@ run_cfg() {   # name scene W H spp(full) spp(profile passes) bench_steps
   cp $OUT/${name}_perf.log $PROF/${TAG}_${name}_quick_perf.jsonl
   python3 tools/quick_perf.py $scene $W $H $pspp > $OUT/${name}_perf_p.log 2>&1
   local slots=$(tail -1 $OUT/${name}_perf_p.log | python3 -c "import json,sys; print(json.loads(sys.stdin.read()).get('path_slots', 0))")
-  local wl="config=$name scene=$scene width=$W height=$H spp=$pspp path_slots=$slots rev=$REV when=$(date +%s)"
+  local wl="config=$name scene=$scene width=$W height=$H spp=$pspp path_slots=$slots rev=$REV build=$BUILD when=$(date +%s)"
   rocprofv3 --kernel-trace --stats -d $OUT/${name}_kt -o kt -- python3 tools/quick_perf.py $scene $W $H $pspp > $OUT/${name}_kt.log 2>&1
   python3 tools/rocpd_export.py stats $OUT/${name}_kt/kt_results.db $PROF/${TAG}_${name}_kernel_stats.csv > $OUT/${name}_kt_stats.txt 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $OUT/${name}_fetch -o p -- python3 tools/quick_perf.py $scene $W $H $pspp > $OUT/${name}_fetch.log 2>&1
