@@ -79,7 +79,7 @@ OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 0))
 # LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
 # silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
 PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4", "LR_HOST_LIB",
-               "LR_ORACLE_LIB")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
+               "LR_ORACLE_LIB", "LR_TAPER", "LR_CHUNK_LEN", "LR_BAND_PIX", "LR_SUB_SHIFT")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
 
 
 def parse():

@@ -147,6 +147,12 @@ struct DevState {
   // a pixel's samples [chunk_start[c], chunk_start[c + 1]) form chunk c (n_chunks + 1 entries; lumilly_hip.hip chunk_schedule: a
   // function of spp only -- long chunks first, a taper of short ones at the end of the render)
   const uint32_t* chunk_start;
+  // Order of the work items of a launch (lr_kernels.h item_decode): SUB-BANDS of 2^sub_shift consecutive pixel ranks, all chunks
+  // of sub-band 0 (chunk-major inside it), then sub-band 1, ...; the last sub-band takes the remainder (one to two sub-bands'
+  // worth of pixels: sub_last_pix from rank sub_last_rank0, its items from sub_last_item0).  sub_shift = 0: one band, item =
+  // chunk * n_pix + rank.  The rays in flight then belong to one strip of the film (L2 locality of tree scenes; the chunk sums
+  // and the film do not depend on it).
+  uint32_t sub_shift, sub_last_item0, sub_last_rank0, sub_last_pix;
   // resident pipeline: a workgroup tops its work-item pool up to pool_low by pool_batch items per iteration.  Paths of
   // one workgroup end their chunks in bursts (they all started together), so an open scene at low spp can ask for a
   // hundred items in one iteration, and a lane that finds the pool empty pays a global atomic round trip inside the

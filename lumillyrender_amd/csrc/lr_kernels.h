@@ -886,6 +886,26 @@ LR_DEV uint32_t rank_to_pixel(const DevState& st, const DevCamera& cam, uint32_t
 // the search runs once per pixel rank per render (k_rank_table); the path kernels read the table
 LR_DEV uint32_t item_pixel(const DevState& st, const DevCamera& cam, uint32_t rank) { (void)cam; return st.rank_pixel[rank]; }
 
+// work item <-> (chunk, pixel rank): DevState "Order of the work items of a launch"
+struct ItemRef { uint32_t chunk, rank; };
+LR_DEV ItemRef item_decode(const DevState& st, uint32_t item) {
+  ItemRef r;
+  const uint32_t shift = fresh_s(st.sub_shift);
+  if (shift == 0u) { const uint32_t n_pix = fresh_s(st.n_pix); r.chunk = item / n_pix; r.rank = item - r.chunk * n_pix; return r; }
+  const uint32_t last0 = st.sub_last_item0;
+  const bool last = item >= last0;                                      // one division serves both cases
+  const uint32_t num = last ? item - last0 : item >> shift, den = last ? st.sub_last_pix : st.n_chunks, quo = num / den, rem = num - quo * den;
+  r.chunk = last ? quo : rem;
+  r.rank = last ? st.sub_last_rank0 + rem : (quo << shift) + (item & ((1u << shift) - 1u));
+  return r;
+}
+LR_DEV size_t item_index(const DevState& st, uint32_t chunk, uint32_t rank) {
+  if (st.sub_shift == 0u) return (size_t)chunk * st.n_pix + rank;
+  if (rank >= st.sub_last_rank0) return (size_t)st.sub_last_item0 + (size_t)chunk * st.sub_last_pix + (rank - st.sub_last_rank0);
+  const uint32_t b = rank >> st.sub_shift;
+  return (((size_t)b * st.n_chunks + chunk) << st.sub_shift) + (rank & ((1u << st.sub_shift) - 1u));
+}
+
 // Start the camera sample (pixel, sample) in `slot`.
 LR_DEV void start_sample(const DevScene& sc, const DevState& st, const DevParams& rp, uint32_t slot, uint32_t pixel, uint32_t sample) {
   Draw4 d0 = rng_block(rp.seed, pixel, sample, 0u);
@@ -942,7 +962,7 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
     if (sc.cam.type == LR_CAMERA_THIN_LENS) delta = (L * g_term) * sc.cam.weight2;   // e * (sens / pdf); 1 * 1 for the others
     sum = v3(a) + delta;
     sample += 1;
-    uint32_t chunk = item / st.n_pix;
+    uint32_t chunk = item_decode(st, item).chunk;
     uint32_t end = st.chunk_start[chunk + 1];
     if (sample >= end) { st.partial[item] = make_float4(sum.x, sum.y, sum.z, 0.0f); need_item = true; }
   }
@@ -958,7 +978,8 @@ LR_DEV bool finish_and_regenerate(const DevScene& sc, const DevState& st, const 
     else if (direct < st.n_items) item = direct;
     else retired = true;
     if (!retired) {
-      uint32_t rank = item % st.n_pix, chunk = item / st.n_pix;
+      const ItemRef ir = item_decode(st, item);
+      const uint32_t rank = ir.rank, chunk = ir.chunk;
       pixel = item_pixel(st, sc.cam, rank);
       sample = st.chunk_start[chunk];
       sum = v3(0, 0, 0);
@@ -1696,7 +1717,10 @@ LR_DEV void pool_step(const DevState& st, PoolLds* pl, uint32_t need, uint32_t b
       if (nb < st.n_items) { pl->r1 = nb; pl->a1 = st.n_items - nb < batch ? st.n_items - nb : batch; }
     }
 #ifdef LR_TIMELINE
-    else { unsigned long long* e = st.timeline + 3 * ((size_t)blockIdx.x * (blockDim.x >> 6)) + 1; if (*e == 0) *e = __builtin_amdgcn_s_memrealtime(); }
+    else {                                                            // first sight of a dry dispenser: when, and what the workgroup still holds
+      unsigned long long* e = st.timeline + 3 * ((size_t)blockIdx.x * (blockDim.x >> 6));
+      if (e[1] == 0) { e[1] = __builtin_amdgcn_s_memrealtime(); e[3 * 2 + 1] = 1 + pl->a0 + pl->a1; e[3 * 3 + 1] = 1 + pl->taken; }
+    }
 #endif
     if (pl->a0 == 0) { pl->r0 = pl->r1; pl->a0 = pl->a1; pl->a1 = 0; }
   }
@@ -1781,6 +1805,9 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   if (tid == 0) pool_step(st, &pl, st.pool_low, st.pool_batch);     // later top-ups happen in phase 2
   uint32_t n_seg = 0, n_shq = 0, n_done = 0, n_sky = 0, parity = 0;
   LR_TL(gst, 0)
+#ifdef LR_TIMELINE
+  uint32_t tl_iter = 0, tl_iter_dry = 0;
+#endif
 #ifdef LR_STAMP
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #define LR_TICK(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tk[i] += t_now - t_prev; t_prev = t_now; }
@@ -1791,6 +1818,10 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
     __syncthreads();                                                // previous iteration (or generation) complete
     LR_TICK(0)
     const uint32_t retired = s_retired;
+#ifdef LR_TIMELINE
+    tl_iter += 1;
+    if (tl_iter_dry == 0 && gst.timeline[3 * ((size_t)blockIdx.x * (RB >> 6)) + 1] != 0) tl_iter_dry = tl_iter;      // (a global read per iteration: diagnostic build)
+#endif
     if (retired >= (uint32_t)RB) break;                          // wave-uniform
     uint32_t* s_cnt = s_cnt2[parity];
     uint32_t* s_cnt_next = s_cnt2[parity ^ 1u];
@@ -1890,6 +1921,9 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   if (lane_id() == 0) for (int i = 0; i < 6; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
 #endif
   LR_TL(gst, 2)
+#ifdef LR_TIMELINE
+  if (tid == 0) gst.timeline[3 * ((size_t)blockIdx.x * (RB >> 6) + 1) + 1] = 1 + (tl_iter_dry ? tl_iter - tl_iter_dry : 0);   // iterations after the dispenser ran dry
+#endif
   stat_accumulate(&s_stat[ST_SEGMENTS], n_seg);
   stat_accumulate(&s_stat[ST_SHADOW], n_shq);
   stat_accumulate(&s_stat[ST_SAMPLES], n_done);
@@ -1908,7 +1942,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(DevScene sc, DevState st, De
   uint32_t stride = gridDim.x * kBlock;
   for (uint32_t rank = blockIdx.x * kBlock + threadIdx.x; rank < st.n_pix; rank += stride) {
     V3 sum = v3(0, 0, 0);
-    for (uint32_t c = 0; c < st.n_chunks; ++c) sum = sum + v3(st.partial[(size_t)c * st.n_pix + rank]);
+    for (uint32_t c = 0; c < st.n_chunks; ++c) sum = sum + v3(st.partial[item_index(st, c, rank)]);
     V3 px = sum / (float)rp.spp;                                       // main.rs:104 / :121
     uint32_t pixel = item_pixel(st, sc.cam, rank);
     float* o = st.film + (size_t)pixel * 3;

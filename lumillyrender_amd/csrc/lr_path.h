@@ -296,8 +296,8 @@ LR_DEV void path_spare_batch(const DevScene& sc, const DevState& st, const DevPa
       else if (k - a0 < a1) item = r1 + (k - a0);
       else retired = true;
       if (!retired) {
-        const uint32_t n_pix = fresh_s(st.n_pix);
-        uint32_t chunk = item / n_pix, rank = item - chunk * n_pix;
+        const ItemRef ir = item_decode(st, item);
+        const uint32_t chunk = ir.chunk, rank = ir.rank;
         pixel = st.rank_pixel[rank];
         sample = st.chunk_start[chunk];
         sp.end[tid] = st.chunk_start[chunk + 1];

@@ -102,7 +102,7 @@ struct LrScene {
   int film_w = 0, film_h = 0;
   int n_prims = 0;
   // render state (kept between calls)
-  DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
+  DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial, partial2;
   DevBuf<float2> hit;
   DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill, chunk_start;
   DevBuf<uint16_t> sort_key, order;
@@ -564,13 +564,16 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
 //          one chunk length throughout that tail was 2-3 chunk times of the slowest lanes with every other lane idle: 3 ms of a
 //          177-ms frame on configs[1], 7.5 ms of 206 on config 3, 14-18 ms on config 5 -- a FIXED cost per call, paid in full by
 //          each rank of an 8-GPU job that renders 1/8 of the frame (profiles/r05_timeline_before.txt: 12 % / 23 % / 6 % there).
-constexpr uint32_t kTaperRepeat = 8;
+constexpr uint32_t kTaperRepeat = 16;
+constexpr uint32_t kSubBandShift = 17;    // work items are dealt in sub-bands of 2^17 consecutive pixel ranks (lr_device.h)
 std::vector<uint32_t> chunk_schedule(uint32_t spp) {
   uint32_t n0 = spp <= 1024 ? std::min<uint32_t>(64, std::max<uint32_t>(1, spp / 8)) : std::min<uint32_t>(256, spp / 16);
-  const uint32_t L = (spp + n0 - 1) / n0;
+  uint32_t L = (spp + n0 - 1) / n0;
   uint32_t level_sum = 0;
-  for (uint32_t l = L / 2; l >= 1; l /= 2) level_sum += l;
   uint32_t R = kTaperRepeat;
+  if (const char* e = std::getenv("LR_TAPER")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) R = (uint32_t)v; }            // diagnostic: chunks per taper level
+  if (const char* e = std::getenv("LR_CHUNK_LEN")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) L = std::min<uint32_t>((uint32_t)v, spp); }   // diagnostic: body chunk length
+  for (uint32_t l = L / 2; l >= 1; l /= 2) level_sum += l;
   if (level_sum == 0) R = 0;
   else R = std::min<uint32_t>(R, spp / (2 * (level_sum + 1)));            // the taper takes at most half of the samples
   const uint32_t taper = R * (level_sum + 1), body = spp - taper;
@@ -620,6 +623,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (rp_in.depth < 0 || rp_in.depth_limit < 0) fail(LR_EINVAL, "negative depth");
   if (n_tiles < 0 || (n_tiles > 0 && !tiles)) fail(LR_EINVAL, "bad tile list");
   HIP_OK(hipSetDevice(s.device));
+  HIP_OK(hipStreamSynchronize(s.stream));                                  // (a call that failed half-way may have left work on the streams)
+  for (auto& g : s.gstream) if (g) HIP_OK(hipStreamSynchronize(g));
   const int W = s.film_w, H = s.film_h;
   // tile list -> prefix of pixel ranks
   std::vector<int4> tl; std::vector<uint32_t> prefix; uint64_t npix64 = 0;
@@ -659,8 +664,26 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   const uint32_t n_chunks = (uint32_t)chunks.size() - 1;
   uint32_t chunk_spp = 1;                                                 // the longest chunk
   for (uint32_t c = 0; c < n_chunks; ++c) chunk_spp = std::max(chunk_spp, chunks[c + 1] - chunks[c]);
-  uint64_t n_items64 = (uint64_t)n_pix * n_chunks;
-  if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items for one call (split the tile list)");
+  // ---- pixel bands --------------------------------------------------------------------------------------------------------
+  // Img::new is W x H (img.rs:13) whatever the spp; the chunk sums of a call are n_pix x n_chunks x 16 B (17 GB for config 5 at
+  // 8192 spp in round 4).  A call whose sums exceed 3 GiB is rendered in BANDS of consecutive pixel ranks -- one launch + one
+  // k_resolve per band, the sums of two bands in flight (1 GiB each), bands alternating between two streams so that the first
+  // workgroups of band b + 1 start on the compute units the last workgroups of band b leave (the tail of a launch is a fixed cost,
+  // see chunk_schedule).  A pixel's samples, chunks and fold order do not depend on the band it falls in: same film bits.  The
+  // rays in flight also stay within one strip of the film instead of all of it (config 5: eight strips render 2.1 % faster than
+  // the whole frame in one launch although each pays its own tail, profiles/r05_locality_c5.json).
+  const uint64_t row_bytes = (uint64_t)n_chunks * sizeof(float4);
+  uint64_t band_budget = 1ull << 30;
+  uint32_t band_pix = n_pix;
+  if ((uint64_t)n_pix * row_bytes > 3 * band_budget) {
+    const uint64_t want = ((uint64_t)n_pix * row_bytes + band_budget - 1) / band_budget;
+    band_pix = (uint32_t)(((uint64_t)n_pix + want - 1) / want);
+  }
+  if (const char* e = std::getenv("LR_BAND_PIX")) { long long v = std::atoll(e); if (v >= 1 && v < (long long)n_pix) band_pix = (uint32_t)v; }   // tests / diagnostics
+  if (band_pix < n_pix) band_pix = (band_pix + 1023u) / 1024u * 1024u;
+  const uint32_t n_bands = n_pix > 0 ? (n_pix + band_pix - 1) / band_pix : 1;
+  uint64_t n_items64 = (uint64_t)std::min(band_pix, n_pix) * n_chunks;      // of one band (the last one may be smaller)
+  if (n_items64 >= 0xffffffffull - (1ull << 24)) fail(LR_EUNSUPPORTED, "too many work items in one band (LR_BAND_PIX too large for this spp)");
   const uint32_t n_items = (uint32_t)n_items64;
   const bool count = (rp_in.flags & LR_FLAG_COUNT) != 0;
   // pipeline: resident (one launch, path state in LDS) when state + traversal stack stay under 40 KB per workgroup
@@ -753,7 +776,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
 
   hipStream_t st = s.stream;
   s.ray_o.ensure(n_slots); s.ray_d.ensure(n_slots); s.hit.ensure(n_slots); s.thr.ensure(n_slots); s.rad.ensure(n_slots);
-  s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
+  s.acc.ensure((size_t)n_slots * 2); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);      // (acc: k_resident keeps its chunk-sum rows here; two bands may be in flight)
   // dense shading (k_shade_all): one launch per iteration over the slots themselves instead of one per class over lists;
   // then k_trace writes no lists and there is ONE shadow list per range (4 B per slot instead of 44)
   const bool dense_shade = !resident && !(std::getenv("LR_DENSE") && std::atoi(std::getenv("LR_DENSE")) == 0);
@@ -766,9 +789,15 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // over the range), so it is opt-in: LR_SORT=1.  DESIGN.md section 6 has the numbers.
   const bool sort_rays = !resident && s.dev.n_flat == 0 && std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 1;
   if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
-  s.counters.ensure(4);
+  s.counters.ensure(4 + (size_t)n_bands);                                     // [0] dispenser (streaming), [1..3] retired slots per group, [4 + b] dispenser of band b
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 64);
   s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
+  const bool overlap_bands = n_bands > 1 && (fused || resident);             // (the streaming pipeline runs its bands one after the other)
+  if (overlap_bands) {
+    s.partial2.ensure(n_items);
+    if (!s.gstream[0]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[0], hipStreamNonBlocking));
+    if (!s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
     HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
@@ -815,7 +844,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   std::memset(&S, 0, sizeof(S)); S.upload_ms = keep_upload; S.bvh_build_ms = keep_bvh;
   S.path_slots = n_slots; S.pipeline = fused ? 2 : (resident ? 1 : 0);
 
-  HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
+  HIP_OK(hipMemsetAsync(s.counters.p, 0, (4 + (size_t)n_bands) * sizeof(uint32_t), st));
   HIP_OK(hipMemsetAsync(s.stats_dev.p, 0, ((size_t)kStatShards * kStatStride + 64) * sizeof(unsigned long long), st));
   HIP_OK(hipEventRecord(s.t_begin, st));
 
@@ -834,7 +863,31 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
   Launcher L{s, profile};
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
-  if (n_items > 0 && fused) {
+  if (overlap_bands) { HIP_OK(hipEventRecord(s.grp_ev[0], st)); HIP_OK(hipStreamWaitEvent(s.gstream[0], s.grp_ev[0], 0)); }   // uploads, memsets, rank table
+  const DevState ds_all = ds;
+  for (uint32_t band = 0; band < n_bands; ++band) {
+  const uint32_t r0 = band * band_pix, bn = std::min(band_pix, n_pix - r0);
+  hipStream_t bst = (overlap_bands && (band & 1u)) ? s.gstream[0] : st;      // the stream this band's launch and resolve go to
+  ds = ds_all;
+  ds.n_pix = bn; ds.n_items = (uint32_t)((uint64_t)bn * n_chunks);
+  {
+    // sub-bands of 2^17 pixel ranks inside the launch (DevState): the rays in flight stay within one strip of the film.  Config 5:
+    // a rank's 1/8 share (524 k pixels spread over the whole film) 271 -> 257 ms, the whole frame -1.2 % (gpurun_out/r05g)
+    uint32_t shift = s.dev.n_flat > 0 ? 0u : kSubBandShift;           // flat scenes have no locality to win (14 primitives in the scalar cache) and pay for the longer decode: config 3 +1.1 %
+    if (const char* e = std::getenv("LR_SUB_SHIFT")) { int v = std::atoi(e); if (v == 0 || (v >= 6 && v <= 30)) shift = (uint32_t)v; }   // diagnostic
+    ds.sub_shift = 0; ds.sub_last_item0 = 0; ds.sub_last_rank0 = 0; ds.sub_last_pix = bn;
+    if (shift > 0 && shift < 31 && (bn >> shift) >= 2u) {
+      const uint32_t full = (bn >> shift) - 1u;                            // the last sub-band takes the remainder too
+      ds.sub_shift = shift; ds.sub_last_rank0 = full << shift; ds.sub_last_pix = bn - ds.sub_last_rank0;
+      ds.sub_last_item0 = (uint32_t)(((uint64_t)full * n_chunks) << shift);
+    }
+  }
+  ds.rank_pixel = s.rank_pixel.p + r0; ds.packed = want_packed ? s.packed.p + (size_t)r0 * 3 : nullptr;
+  ds.partial = (overlap_bands && (band & 1u)) ? s.partial2.p : s.partial.p;
+  if (fused || resident) ds.next_item = s.counters.p + 4 + band;
+  if (overlap_bands && (band & 1u)) ds.acc = ds_all.acc + (size_t)n_slots;
+  else if (band > 0) HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
+  if (ds.n_items > 0 && fused) {
     const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
     // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
     ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
@@ -843,30 +896,29 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     while ((1ull << ds.pool_shift) < 2ull * n_waves) ++ds.pool_shift;     // 2 x the waves that draw from the dispenser
     if (s.dev.n_flat == 0) {
       dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
-      if (dsc.spill_depth > 0) {
-        s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
-        dsc.stack_spill = s.stack_spill.p;
+      if (dsc.spill_depth > 0) {                                         // (two bands in flight: each launch its own spill rows)
+        const size_t per_launch = (size_t)blocks * dsc.spill_depth * kBlock;
+        s.stack_spill.ensure(per_launch * (overlap_bands ? 2 : 1));
+        dsc.stack_spill = s.stack_spill.p + ((overlap_bands && (band & 1u)) ? per_launch : 0);
       }
     }
     const float4* flat_rows = (const float4*)s.flat.p;
     void* args[4] = {&dsc, &ds, &dp, (void*)&flat_rows};                // k_path_tree takes the first three
-    L.run(LR_K_PATH, [&] { HIP_OK(hipLaunchKernel(fused_kernel, dim3(blocks), dim3(kBlock), args, fused_lds, st)); });
+    L.run(LR_K_PATH, [&] { HIP_OK(hipLaunchKernel(fused_kernel, dim3(blocks), dim3(kBlock), args, fused_lds, bst)); }, bst);
     S.iterations = 1;
-    HIP_OK(hipStreamSynchronize(st));
-  } else if (n_items > 0 && resident) {
+  } else if (ds.n_items > 0 && resident) {
     uint32_t mt_mask = 0;
     for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
     if (RB == 512) { ds.pool_batch *= 2; ds.pool_low *= 2; }
     auto launch_resident = [&](auto kernel) {
       HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / RB), dim3(RB), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
+      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / RB), dim3(RB), resident_lds, bst, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); }, bst);
     };
     if (s.dev.n_flat > 0 && mt_mask == 1u) { if (RB == 512) launch_resident(k_resident<true, 1u, 512>); else launch_resident(k_resident<true, 1u, 256>); }   // flat, Lambert only
     else if (s.dev.n_flat > 0) { if (RB == 512) launch_resident(k_resident<true, 31u, 512>); else launch_resident(k_resident<true, 31u, 256>); }
     else launch_resident(k_resident<false, 31u, 256>);
     S.iterations = 1;
-    HIP_OK(hipStreamSynchronize(st));
-  } else if (n_items > 0) {
+  } else if (ds.n_items > 0) {
     // Two slot groups on two streams: the traversal kernels are latency- and divergence-bound, the shade kernels
     // bandwidth-bound, so whenever the two groups are out of phase one's k_trace overlaps the other's k_shade
     // (+10 % on the mesh configs, free-running; chaining the traces with events so that they alternate strictly,
@@ -995,10 +1047,12 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     HIP_OK(hipStreamSynchronize(st));
     if (!retired_all(&s.pinned[((batch - 1) & 1) * 4])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
   }
-  if (n_pix > 0) {
-    int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, n_pix);
-    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, dsc, ds, dp); });
+  if (bn > 0) {
+    int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, bn);
+    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, bst, dsc, ds, dp); }, bst);
   }
+  }   // bands
+  if (overlap_bands) { HIP_OK(hipEventRecord(s.grp_ev[1], s.gstream[0])); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[1], 0)); }
   HIP_OK(hipEventRecord(s.t_end, st));
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
   HIP_OK(hipMemcpyAsync(hshards, s.stats_dev.p, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1015,7 +1069,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     for (size_t w = 0; w < nw; ++w) {
       if (!tl[3 * w] || !tl[3 * w + 2]) continue;
       en.push_back((tl[3 * w] - t0) * 1e-5); ex.push_back((tl[3 * w + 2] - t0) * 1e-5);
-      if (tl[3 * w + 1]) dr.push_back((tl[3 * w + 1] - t0) * 1e-5);
+      if (tl[3 * w + 1] && (!resident || w % (RB / 64) == 0)) dr.push_back((tl[3 * w + 1] - t0) * 1e-5);
       busy += (tl[3 * w + 2] - tl[3 * w]) * 1e-5;
     }
     std::sort(en.begin(), en.end()); std::sort(dr.begin(), dr.end()); std::sort(ex.begin(), ex.end());
@@ -1025,6 +1079,13 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
                  "\"exit_ms\": [%.3f, %.3f, %.3f, %.3f, %.3f, %.3f, %.3f], \"wave_time_over_span\": %.4f, \"quantiles\": \"entry 0.5 0.9 0.99 1 | dry 0 0.5 1 | exit 0 0.01 0.1 0.5 0.9 0.99 1\"}\n",
                  en.size(), span, q(en, 0.5), q(en, 0.9), q(en, 0.99), q(en, 1.0), q(dr, 0.0), q(dr, 0.5), q(dr, 1.0),
                  q(ex, 0.0), q(ex, 0.01), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 0.99), q(ex, 1.0), en.empty() ? 0.0 : busy / (en.size() * span));
+    if (resident) {                                                    // per workgroup: iterations after dry, items in the pool at dry, drawn but not yet accounted
+      std::vector<double> it, po, tk;
+      for (size_t w = 0; w + 3 < nw; w += RB / 64) { if (tl[3 * (w + 1) + 1]) it.push_back((double)tl[3 * (w + 1) + 1] - 1); if (tl[3 * (w + 2) + 1]) po.push_back((double)tl[3 * (w + 2) + 1] - 1); if (tl[3 * (w + 3) + 1]) tk.push_back((double)tl[3 * (w + 3) + 1] - 1); }
+      std::sort(it.begin(), it.end()); std::sort(po.begin(), po.end()); std::sort(tk.begin(), tk.end());
+      std::fprintf(stderr, "[LR_TIMELINE] resident workgroups (%d slots): iterations after dry [%.0f, %.0f, %.0f, %.0f], pooled items at dry [%.0f, %.0f, %.0f], taken [%.0f, %.0f] (quantiles 0.1 0.5 0.9 1 | 0.1 0.5 1 | 0.5 1)\n",
+                   RB, q(it, 0.1), q(it, 0.5), q(it, 0.9), q(it, 1.0), q(po, 0.1), q(po, 0.5), q(po, 1.0), q(tk, 0.5), q(tk, 1.0));
+    }
   }
 #endif
 #ifdef LR_STAMP
@@ -1137,9 +1198,10 @@ int lr_scene_destroy(LrScene* s) {
   if (!s) return LR_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (auto& g : s->gstream) if (g) (void)hipStreamSynchronize(g);
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->texels_rgbe.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release(); s->chunk_start.release();
+  s->partial.release(); s->partial2.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release(); s->chunk_start.release();
   s->stats_dev.release(); s->film.release(); s->packed.release(); s->sort_key.release(); s->order.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->host_film) (void)hipHostFree(s->host_film);
