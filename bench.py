@@ -74,12 +74,12 @@ CONFIGS = {
            "Msamples/sec (whole node), welcome-2018-class 2048x2048 8192 spp IBL"),
 }
 # legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp).  Every leg runs at its STATED size, warm-up
-# frame included (the chunk-sum buffer is sized by spp: a shorter warm-up left its allocation -- 17 GB for C5 -- in the timed frame)
-OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 1, 1, 0), ("c5", 1, 1, 0))
+# frame included (buffers sized by the frame -- the chunk sums of a band, up to 2 x 1 GiB -- are allocated in the warm-up frame, not in the timed one)
+OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 2, 1, 0), ("c5", 1, 1, 0))
 # LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
 # silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
 PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4", "LR_HOST_LIB",
-               "LR_ORACLE_LIB", "LR_TAPER", "LR_CHUNK_LEN", "LR_BAND_PIX", "LR_SUB_SHIFT")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
+               "LR_ORACLE_LIB", "LR_TAPER", "LR_CHUNK_LEN", "LR_BAND_PIX", "LR_SUB_SHIFT", "LR_CULL_SLACK")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
 
 
 def parse():
@@ -241,6 +241,7 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
                 "measured_hbm_GBps": round(measured_gbps, 2) if measured_gbps else None,
                 "measured_hbm_frac": round(measured_gbps / HBM_PEAK_GBS, 5) if measured_gbps else None,
                 "avg_launch_ms": round(avg_ms, 5), "timed_launches": acc["kernel_timed"][dom],
+                "launches_per_frame": round(acc["kernel_launches"][dom] / max(acc["samples"] / (float(W) * H * spp), 1e-9), 2),
                 "valu_wave_instr_per_launch": valu, "transcendental_per_launch": trans,
                 "clock_GHz_in_pmc_pass": round(clock_ghz, 3), "source": os.path.relpath(gotp[0], ROOT),
                 # the instruction counts are the committed pass's: `profile_current` says whether that pass was taken on the library
@@ -272,7 +273,9 @@ def roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, ti
     scene_bytes_per_q = NODE_BYTES_PER_CHILD_BOX * v_per_q + PRIM_BYTES * t_per_q / (64.0 if flat else 1.0)
     bytes_per_sample = 224.0 * s_per + 108.0 * q_per + scene_bytes_per_q * (s_per + q_per) + 12.0 / spp
     if one_launch:
-        units, unit_name = float(W) * H * spp, "camera samples"
+        # a frame whose chunk sums exceed 3 GiB is rendered in pixel bands, one launch each (lumilly_hip.hip): camera samples per
+        # launch = the timed frames' samples over the timed frames' launches of this kernel
+        units, unit_name = acc["samples"] / max(acc["kernel_launches"][dom], 1), "camera samples"
         bytes_per_launch = bytes_per_sample * units
     elif dom == abi.LR_K_SHADOW:
         units, unit_name = acc["shadow"] / max(acc["kernel_launches"][dom], 1), "shadow rays"

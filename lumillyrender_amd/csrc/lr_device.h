@@ -5,7 +5,7 @@
 //           plane on a power-of-two grid anchored at the node's lower corner:
 //             {origin.xyz, ex | ey << 8 | ez << 16}       e* = IEEE biased exponents of the grid steps 2^(e - 127)
 //             {qlo.x of child 0..3 (one byte each), qlo.y, qlo.z, qhi.x}
-//             {qhi.y, qhi.z, no-distance-culling flag (a sliver triangle below this node, see lr_scene_create), -}
+//             {qhi.y, qhi.z, 2 kappa, kappa * diagonal}     the distance-culling slack of this node's children (lr_scene_create, Wide4Builder)
 //             {child 0..3 as int bits}
 //           plane = origin + q * step; lower planes are rounded down, upper planes up, so a stored box contains the
 //           padded f32 box of the description.  child >= 0 inner node, child < 0 leaf ~c = first<<3 | count,

@@ -219,7 +219,10 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
     // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far -- none below a node that
     // holds a sliver triangle (lr_scene_create sets qb.z): its Moeller-Trumbore distance may land in front of its own box
-    const float bound = __float_as_uint(qb.z) != 0u ? inf : (SHADOW ? s.dist + 2.0f * kEps : s.t);
+    // (+ the culling slack of this node, lumilly_hip.hip Wide4Builder: a child is culled when it begins beyond
+    //  bound + kappa * diagonal + 2 kappa * t_far(child), the error bound of any Moeller-Trumbore distance inside it)
+    const float bound = (SHADOW ? s.dist + 2.0f * kEps : s.t) + qb.w;
+    const float slack2 = qb.z;
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
@@ -232,7 +235,8 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
       float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
       float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
       float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
-      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, bound));                            \
+      float tfr = __builtin_fminf(__builtin_fminf(a1, b1), c1);                                                  \
+      float tf = __builtin_fminf(tfr, __builtin_fmaf(slack2, tfr, bound));                                       \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
     LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)

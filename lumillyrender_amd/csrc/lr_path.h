@@ -564,7 +564,8 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, const LS& ls, bool conn, ui
     const float ax = __uint_as_float((eb & 0xffu) << 23) * s.ix, bx = (g.x - o.x) * s.ix;
     const float ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * s.iy, by = (g.y - o.y) * s.iy;
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - o.z) * s.iz;
-    const float bound = __float_as_uint(qb.z) != 0u ? inf : ((CONN && conn) ? ls.sh_d.v.w + 2.0f * kEps : s.t);   // as trav_node
+    const float bound = ((CONN && conn) ? ls.sh_d.v.w + 2.0f * kEps : s.t) + qb.w;   // as trav_node
+    const float slack2 = qb.z;
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
     const uint32_t wlx = __float_as_uint(qa.x), wly = __float_as_uint(qa.y), wlz = __float_as_uint(qa.z);
     const uint32_t whx = __float_as_uint(qa.w), why = __float_as_uint(qb.x), whz = __float_as_uint(qb.y);
@@ -577,7 +578,8 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, const LS& ls, bool conn, ui
       float b0 = __builtin_fmaf(qbyte(ny, C), ay, by), b1 = __builtin_fmaf(qbyte(fy, C), ay, by);                \
       float c0 = __builtin_fmaf(qbyte(nz, C), az, bz), c1 = __builtin_fmaf(qbyte(fz, C), az, bz);                \
       float tn = __builtin_fmaxf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(c0, 0.0f));                            \
-      float tf = __builtin_fminf(__builtin_fminf(a1, b1), __builtin_fminf(c1, bound));                            \
+      float tfr = __builtin_fminf(__builtin_fminf(a1, b1), c1);                                                  \
+      float tf = __builtin_fminf(tfr, __builtin_fmaf(slack2, tfr, bound));                                       \
       K = (tn <= tf && R != kEmptyChild) ? tn : inf;                                                             \
     }
     LR_SLAB(k0, 0, r0) LR_SLAB(k1, 1, r1) LR_SLAB(k2, 2, r2) LR_SLAB(k3, 3, r3)

@@ -68,7 +68,11 @@ struct DevBuf {
   void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
 };
 
-constexpr double kSliverInvSin = 8.0;   // triangles with sin(angle at p0) < 1/8 are exempt from distance culling
+constexpr double kSliverInvSin = 8.0;   // (statistics only since round 5: triangles with sin(angle at p0) < 1/8, lr_selftest_tree_info)
+constexpr double kCullSlack = 24.0;     // distance culling keeps kCullSlack eps |e1||e2| (|o - p0| + |t|) / 1e-3 of slack per child (Wide4Builder).  First-order
+                                        // analysis of triangle.rs:69-100 in f32: |dN| <= 7.5 eps A |tv|, |d det| <= 7.5 eps A, t = N / det => |dt| <= 7.5 eps A (|tv| + |t|) / |det|
+                                        // + 2 eps |t|: a factor 3 of margin.  Measured (gpurun_out/r05j): 0 / 24 / 64 / 200 render config 4 at 4166 / 4086 / 4036 / 3912
+                                        // Msamples/s (round 4's sliver flag: 4101) and config 5 at 4099 / 4034 / 4003 / 3943 (4072)
 constexpr int kEventPool = 1024;      // timed launches per kernel type per render
 constexpr int kProfileStride = 2;     // time every 2nd iteration when LR_FLAG_PROFILE is set
 
@@ -97,7 +101,7 @@ struct LrScene {
   DevScene dev;
   bool mat_present[kNumShadeQueues] = {false, false, false, false, false, true};
   int stack_depth = 2;
-  int tree_info[4] = {0, 0, 0, 0};     // 4-wide nodes, nodes without distance culling (a sliver triangle below them), sliver triangles, stack need
+  int tree_info[4] = {0, 0, 0, 0};     // 4-wide nodes, nodes whose culling slack exceeds the distance itself (2 kappa >= 1: a wall-sized triangle below), sliver triangles, stack need
   double bvh_build_ms = 0.0;           // device LBVH build time (0 when the host supplied the tree)
   int film_w = 0, film_h = 0;
   int n_prims = 0;
@@ -138,11 +142,18 @@ namespace {
 struct Wide4Builder {
   const std::vector<float4>& in;
   std::vector<float4>& out;
-  // leaf_flag[k] != 0: the primitive at leaf position k is a triangle whose Moeller-Trumbore distance is ill-conditioned for
-  // every direction (a sliver at its first vertex, see pack_scene).  A node with such a leaf anywhere below it is stored with
-  // its "no distance culling" word set: bvh.rs:131-141 tests every leaf whose box the ray touches, however far behind the
-  // closest hit so far it begins, and only for these triangles can the reported distance land in front of their own box.
-  const std::vector<uint8_t>* leaf_flag = nullptr;
+  // leaf_area[k] = |e1||e2| of the triangle at leaf position k (0 for a sphere).  bvh.rs:131-141 tests every leaf whose box the
+  // ray touches, however far behind the closest hit so far it begins; a traversal that culls by distance assumes an accepted hit
+  // lies inside its primitive's box.  Moeller-Trumbore's distance t = (e2 . qv) / det carries an absolute error of up to
+  // ~12 eps |e1||e2| (|o - p0| + |t|) / |det| and triangle.rs:75 accepts |det| down to an ABSOLUTE 1e-3, so a hit at grazing
+  // incidence can be reported in front of its own (padded) box -- by 5 triangle sizes in round 4's fuzz.  Every node therefore
+  // carries kappa = kCullSlack (= 24) eps max|e1||e2| / 1e-3 over the triangles below it, and a child is culled only when it begins
+  // beyond   bound + kappa (2 t_far(child) + diagonal(node))   -- the error bound of any triangle inside that child, with
+  // |o - p0| <= t_far + diagonal and |t| <= t_far.  For a well-conditioned mesh kappa is ~1e-2 (a few units of slack at the
+  // scales of the BASELINE scenes: +2-3 % node visits); for a wall-sized triangle it is so large that nothing below the nodes that
+  // hold it is culled by distance -- the reference's rule for that subtree.  Replaces round 3's sliver flag (sin(phi) < 1/8: a
+  // heuristic on the shape; the bound above covers slivers through |det| >= 1e-3 like every other triangle).
+  const std::vector<float>* leaf_area = nullptr;
   struct Cand { float lo[3], hi[3]; int ref; };
   static float area(const Cand& c) {
     float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
@@ -153,9 +164,9 @@ struct Wide4Builder {
     two[0] = Cand{{x.x, y.x, z.x}, {x.y, y.y, z.y}, __builtin_bit_cast(int, c.x)};
     two[1] = Cand{{x.z, y.z, z.z}, {x.w, y.w, z.w}, __builtin_bit_cast(int, c.y)};
   }
-  int build(int node, int* need_out, bool* flagged_out = nullptr) {
+  int build(int node, int* need_out, float* amax_out = nullptr) {
     const size_t me = out.size() / kNodeRows;
-    bool flagged = false;
+    float amax = 0.0f;                                                   // max |e1||e2| over the triangles below this node
     out.resize(out.size() + kNodeRows, make_float4(0, 0, 0, 0));
     Cand c[4]; int n = 2;
     children(node, c);
@@ -172,12 +183,12 @@ struct Wide4Builder {
       int ref = kEmptyChild;
       if (k < n) {
         ref = c[k].ref;
-        if (ref >= 0) { int sub = 0; bool f = false; ref = build(ref, &sub, &f); flagged = flagged || f; need = std::max(need, n - 1 + sub); }
+        if (ref >= 0) { int sub = 0; float a = 0.0f; ref = build(ref, &sub, &a); amax = std::fmax(amax, a); need = std::max(need, n - 1 + sub); }
         else {
           need = std::max(need, n - 1);
-          if (leaf_flag && ref != kEmptyChild) {
+          if (leaf_area && ref != kEmptyChild) {
             const uint32_t enc = (uint32_t)~ref, first = enc >> 3, count = enc & 7u;
-            for (uint32_t q = first; q < first + count && q < leaf_flag->size(); ++q) flagged = flagged || (*leaf_flag)[q] != 0;
+            for (uint32_t q = first; q < first + count && q < leaf_area->size(); ++q) amax = std::fmax(amax, (*leaf_area)[q]);
           }
         }
       }
@@ -185,12 +196,14 @@ struct Wide4Builder {
     }
     // grid: origin = the lower corner of the union (an f32), step 2^e per axis with 255 steps covering the extent
     float org[3]; uint32_t ebits = 0; uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    double diag2 = 0.0;
     for (int a = 0; a < 3; ++a) {
       float lo = c[0].lo[a], hi = c[0].hi[a];
       for (int k = 1; k < n; ++k) { lo = std::fmin(lo, c[k].lo[a]); hi = std::fmax(hi, c[k].hi[a]); }
       if (!(std::fabs(lo) < INFINITY) || !(std::fabs(hi) < INFINITY) || hi < lo) fail(LR_EINVAL, "BVH box is not finite");
       org[a] = lo;
       const double ext = (double)hi - (double)lo;
+      diag2 += ext * ext;
       int e = -126;
       if (ext > 0.0) { int ex; (void)std::frexp(ext / 255.0, &ex); e = ex; }          // 2^ex > ext / 255 >= 2^(ex-1)
       if (e > 40) fail(LR_EUNSUPPORTED, "scene extent beyond 2^48: outside the range the traversal arithmetic keeps finite");
@@ -215,10 +228,15 @@ struct Wide4Builder {
     auto fb = [](uint32_t u) { return __builtin_bit_cast(float, u); };
     out[me * kNodeRows + 0] = make_float4(org[0], org[1], org[2], fb(ebits));
     out[me * kNodeRows + 1] = make_float4(fb(qlo[0]), fb(qlo[1]), fb(qlo[2]), fb(qhi[0]));
-    out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), fb(flagged ? 1u : 0u), 0.0f);
+    // the culling slack of this node's children: lim = bound + kappa * diagonal + 2 kappa * t_far(child)  (finite: no inf - inf on the device)
+    double slack_k = kCullSlack;
+    if (const char* e = std::getenv("LR_CULL_SLACK")) slack_k = std::atof(e);          // diagnostic
+    const double kappa = std::isfinite(amax) ? slack_k * 5.9604644775390625e-8 * (double)amax / 1.0e-3 : 1.0e12;
+    const float k2 = (float)std::fmin(2.0 * kappa, 1.0e12), kd = (float)std::fmin(kappa * std::sqrt(diag2), 1.0e30);
+    out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), k2, kd);
     out[me * kNodeRows + 3] = make_float4(fb((uint32_t)refs[0]), fb((uint32_t)refs[1]), fb((uint32_t)refs[2]), fb((uint32_t)refs[3]));
     *need_out = need;
-    if (flagged_out) *flagged_out = flagged;
+    if (amax_out) *amax_out = amax;
     return (int)me;
   }
 };
@@ -251,6 +269,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   std::vector<uint8_t> qid((size_t)np);
   std::vector<float> area((size_t)np);
   std::vector<uint8_t> sliver((size_t)np, 0);
+  std::vector<float> tri_a((size_t)np, 0.0f);                        // |e1||e2| per triangle (0 for spheres): the scale of Moeller-Trumbore's absolute error
   for (int q = 0; q < kNumShadeQueues - 1; ++q) s.mat_present[q] = false;
   for (int i = 0; i < np; ++i) {
     const LrPrimitive& p = d.prims[i];
@@ -274,6 +293,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
         const double cx = (double)e1[1] * e2[2] - (double)e1[2] * e2[1], cy = (double)e1[2] * e2[0] - (double)e1[0] * e2[2], cz = (double)e1[0] * e2[1] - (double)e1[1] * e2[0];
         const double sinphi_l1l2 = std::sqrt(cx * cx + cy * cy + cz * cz);
         sliver[i] = !(sinphi_l1l2 * kSliverInvSin >= l1 * l2) ? 1 : 0;     // sin(phi) < 1 / kSliverInvSin (also degenerate / NaN)
+        tri_a[i] = (float)(l1 * l2 * (1.0 + 1e-6));
       }
     } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
       shade[4 * i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
@@ -437,32 +457,28 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       HIP_OK(hipMemcpyAsync(nodes.data(), s.nodes.p, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
       HIP_OK(hipStreamSynchronize(s.stream));
     }
-    // leaf position -> sliver flag (leaf order: the description's permutation, or the ids the device builder left in the rows)
-    std::vector<uint8_t> leaf_flag((size_t)std::max(np, 1), 0);
-    bool any_sliver = false;
-    for (int i = 0; i < np; ++i) any_sliver = any_sliver || sliver[i];
-    if (any_sliver) {
-      if (built_on_device) {
-        std::vector<float4> rows((size_t)np * 3);
-        HIP_OK(hipMemcpyAsync(rows.data(), s.prims.p, rows.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
-        HIP_OK(hipStreamSynchronize(s.stream));
-        for (int k = 0; k < np; ++k) { uint32_t id = __builtin_bit_cast(uint32_t, rows[3 * (size_t)k].w) & 0x7fffffffu; if (id < (uint32_t)np) leaf_flag[k] = sliver[id]; }
-      } else if (!device_bvh) {
-        for (int k = 0; k < np; ++k) leaf_flag[k] = sliver[d.bvh_prim_order[k]];
-      } else if (np == 1) leaf_flag[0] = sliver[0];
-    }
+    // leaf position -> |e1||e2| of the triangle there (leaf order: the description's permutation, or the ids the device builder left in the rows)
+    std::vector<float> leaf_area((size_t)std::max(np, 1), 0.0f);
+    if (built_on_device) {
+      std::vector<float4> rows((size_t)np * 3);
+      HIP_OK(hipMemcpyAsync(rows.data(), s.prims.p, rows.size() * sizeof(float4), hipMemcpyDeviceToHost, s.stream));
+      HIP_OK(hipStreamSynchronize(s.stream));
+      for (int k = 0; k < np; ++k) { uint32_t id = __builtin_bit_cast(uint32_t, rows[3 * (size_t)k].w) & 0x7fffffffu; if (id < (uint32_t)np) leaf_area[k] = tri_a[id]; }
+    } else if (!device_bvh) {
+      for (int k = 0; k < np; ++k) leaf_area[k] = tri_a[d.bvh_prim_order[k]];
+    } else if (np == 1) leaf_area[0] = tri_a[0];
     std::vector<float4> wide;
     wide.reserve(nodes.size());
     int need = 0;
     Wide4Builder w4{nodes, wide};
-    w4.leaf_flag = any_sliver ? &leaf_flag : nullptr;
+    w4.leaf_area = &leaf_area;
     w4.build(0, &need);
     if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
     s.stack_depth = need + 1;
     {
       size_t n_sliver = 0, n_nocull = 0;
       for (int i = 0; i < np; ++i) n_sliver += sliver[i];
-      for (size_t k = 0; k < wide.size() / kNodeRows; ++k) n_nocull += __builtin_bit_cast(uint32_t, wide[k * kNodeRows + 2].z) != 0u;
+      for (size_t k = 0; k < wide.size() / kNodeRows; ++k) n_nocull += wide[k * kNodeRows + 2].z >= 1.0f;      // 2 kappa >= 1: the slack exceeds the child's own distance, i.e. no culling
       s.tree_info[0] = (int)(wide.size() / kNodeRows); s.tree_info[1] = (int)n_nocull; s.tree_info[2] = (int)n_sliver; s.tree_info[3] = need;
       if (std::getenv("LR_DEBUG")) std::fprintf(stderr, "[lr] wide BVH: %zu binary nodes -> %zu 4-wide nodes of %d B, stack need %d; %zu sliver triangles, %zu nodes without distance culling\n",
                    nodes.size() / 4, wide.size() / kNodeRows, kNodeRows * 16, need, n_sliver, n_nocull);

@@ -213,7 +213,7 @@ class Scene:
         return out
 
     def tree_info(self):
-        """{nodes, nodes_without_distance_culling, sliver_triangles, stack_need} of the scene's 4-wide tree."""
+        """{nodes, nodes_without_distance_culling (culling slack >= the distance itself), sliver_triangles, stack_need} of the scene's 4-wide tree."""
         out = (C.c_int32 * 4)()
         _check(lib().lr_selftest_tree_info(self._h, out))
         return {"nodes": out[0], "nodes_without_distance_culling": out[1], "sliver_triangles": out[2], "stack_need": out[3]}
