@@ -106,7 +106,7 @@ struct LrScene {
   int film_w = 0, film_h = 0;
   int n_prims = 0;
   // render state (kept between calls)
-  DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial, partial2;
+  DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
   DevBuf<uint32_t> q_shade, c_shade, q_shadow, c_shadow, counters, tile_prefix, rank_pixel, stack_spill, chunk_start;
   DevBuf<uint16_t> sort_key, order;
@@ -682,16 +682,17 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   for (uint32_t c = 0; c < n_chunks; ++c) chunk_spp = std::max(chunk_spp, chunks[c + 1] - chunks[c]);
   // ---- pixel bands --------------------------------------------------------------------------------------------------------
   // Img::new is W x H (img.rs:13) whatever the spp; the chunk sums of a call are n_pix x n_chunks x 16 B (17 GB for config 5 at
-  // 8192 spp in round 4).  A call whose sums exceed 3 GiB is rendered in BANDS of consecutive pixel ranks -- one launch + one
-  // k_resolve per band, the sums of two bands in flight (1 GiB each), bands alternating between two streams so that the first
-  // workgroups of band b + 1 start on the compute units the last workgroups of band b leave (the tail of a launch is a fixed cost,
-  // see chunk_schedule).  A pixel's samples, chunks and fold order do not depend on the band it falls in: same film bits.  The
-  // rays in flight also stay within one strip of the film instead of all of it (config 5: eight strips render 2.1 % faster than
-  // the whole frame in one launch although each pays its own tail, profiles/r05_locality_c5.json).
+  // 8192 spp in round 4).  A call whose sums exceed 3 GiB is rendered in BANDS of consecutive pixel ranks with at most 2 GiB of sums
+  // each -- one launch + one k_resolve per band, one after the other on the call's stream.  A pixel's samples, chunks and fold
+  // order do not depend on the band it falls in: same film bits.  The tail a band adds is short (chunk_schedule's taper) and the
+  // bands keep the rays in flight within a strip of the film: measured against one launch for the whole frame, config 4 (8 bands)
+  // 1317.6 vs 1315.3 ms, config 5 at 2048 spp (12 bands) 2038.8 vs 2055.8 ms.  (Two bands in flight on two streams -- the first
+  // workgroups of band b + 1 starting on the compute units the last ones of band b leave -- was built and measured: 1314.9 / 2055.8 ms,
+  // no better, and every launch's dispatch-to-end time then includes its wait for the previous band: gpurun_out/r05l.)
   const uint64_t row_bytes = (uint64_t)n_chunks * sizeof(float4);
-  uint64_t band_budget = 1ull << 30;
+  const uint64_t band_budget = 2ull << 30;                                 // chunk sums of one band
   uint32_t band_pix = n_pix;
-  if ((uint64_t)n_pix * row_bytes > 3 * band_budget) {
+  if ((uint64_t)n_pix * row_bytes > band_budget + (band_budget >> 1)) {          // (a call up to 3 GiB stays one launch)
     const uint64_t want = ((uint64_t)n_pix * row_bytes + band_budget - 1) / band_budget;
     band_pix = (uint32_t)(((uint64_t)n_pix + want - 1) / want);
   }
@@ -792,7 +793,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
 
   hipStream_t st = s.stream;
   s.ray_o.ensure(n_slots); s.ray_d.ensure(n_slots); s.hit.ensure(n_slots); s.thr.ensure(n_slots); s.rad.ensure(n_slots);
-  s.acc.ensure((size_t)n_slots * 2); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);      // (acc: k_resident keeps its chunk-sum rows here; two bands may be in flight)
+  s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
   // dense shading (k_shade_all): one launch per iteration over the slots themselves instead of one per class over lists;
   // then k_trace writes no lists and there is ONE shadow list per range (4 B per slot instead of 44)
   const bool dense_shade = !resident && !(std::getenv("LR_DENSE") && std::atoi(std::getenv("LR_DENSE")) == 0);
@@ -808,12 +809,6 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.counters.ensure(4 + (size_t)n_bands);                                     // [0] dispenser (streaming), [1..3] retired slots per group, [4 + b] dispenser of band b
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 64);
   s.partial.ensure(n_items); s.rank_pixel.ensure(std::max<uint32_t>(n_pix, 1));
-  const bool overlap_bands = n_bands > 1 && (fused || resident);             // (the streaming pipeline runs its bands one after the other)
-  if (overlap_bands) {
-    s.partial2.ensure(n_items);
-    if (!s.gstream[0]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[0], hipStreamNonBlocking));
-    if (!s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
   if (s.film.n < (size_t)W * H * 3 || !s.film.p) {
     s.film.ensure((size_t)W * H * 3);
     HIP_OK(hipMemsetAsync(s.film.p, 0, (size_t)W * H * 3 * sizeof(float), st));
@@ -879,11 +874,10 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   dsc.stack_lds = stack_in_lds; dsc.spill_depth = s.stack_depth - stack_in_lds; dsc.stack_spill = nullptr;
   Launcher L{s, profile};
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
-  if (overlap_bands) { HIP_OK(hipEventRecord(s.grp_ev[0], st)); HIP_OK(hipStreamWaitEvent(s.gstream[0], s.grp_ev[0], 0)); }   // uploads, memsets, rank table
   const DevState ds_all = ds;
   for (uint32_t band = 0; band < n_bands; ++band) {
   const uint32_t r0 = band * band_pix, bn = std::min(band_pix, n_pix - r0);
-  hipStream_t bst = (overlap_bands && (band & 1u)) ? s.gstream[0] : st;      // the stream this band's launch and resolve go to
+  hipStream_t bst = st;
   ds = ds_all;
   ds.n_pix = bn; ds.n_items = (uint32_t)((uint64_t)bn * n_chunks);
   {
@@ -899,9 +893,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     }
   }
   ds.rank_pixel = s.rank_pixel.p + r0; ds.packed = want_packed ? s.packed.p + (size_t)r0 * 3 : nullptr;
-  ds.partial = (overlap_bands && (band & 1u)) ? s.partial2.p : s.partial.p;
   if (fused || resident) ds.next_item = s.counters.p + 4 + band;
-  if (overlap_bands && (band & 1u)) ds.acc = ds_all.acc + (size_t)n_slots;
   else if (band > 0) HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
   if (ds.n_items > 0 && fused) {
     const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
@@ -912,10 +904,9 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     while ((1ull << ds.pool_shift) < 2ull * n_waves) ++ds.pool_shift;     // 2 x the waves that draw from the dispenser
     if (s.dev.n_flat == 0) {
       dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
-      if (dsc.spill_depth > 0) {                                         // (two bands in flight: each launch its own spill rows)
-        const size_t per_launch = (size_t)blocks * dsc.spill_depth * kBlock;
-        s.stack_spill.ensure(per_launch * (overlap_bands ? 2 : 1));
-        dsc.stack_spill = s.stack_spill.p + ((overlap_bands && (band & 1u)) ? per_launch : 0);
+      if (dsc.spill_depth > 0) {
+        s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
+        dsc.stack_spill = s.stack_spill.p;
       }
     }
     const float4* flat_rows = (const float4*)s.flat.p;
@@ -1068,7 +1059,6 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, bst, dsc, ds, dp); }, bst);
   }
   }   // bands
-  if (overlap_bands) { HIP_OK(hipEventRecord(s.grp_ev[1], s.gstream[0])); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[1], 0)); }
   HIP_OK(hipEventRecord(s.t_end, st));
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);
   HIP_OK(hipMemcpyAsync(hshards, s.stats_dev.p, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1217,7 +1207,7 @@ int lr_scene_destroy(LrScene* s) {
   for (auto& g : s->gstream) if (g) (void)hipStreamSynchronize(g);
   s->nodes.release(); s->prims.release(); s->flat.release(); s->shade.release(); s->emit.release(); s->texels.release(); s->texels_rgbe.release(); s->prim_qid.release();
   s->ray_o.release(); s->ray_d.release(); s->thr.release(); s->rad.release(); s->acc.release(); s->sh_d.release(); s->sh_w.release();
-  s->partial.release(); s->partial2.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release(); s->chunk_start.release();
+  s->partial.release(); s->hit.release(); s->q_shade.release(); s->c_shade.release(); s->q_shadow.release(); s->c_shadow.release(); s->pool.release(); s->counters.release(); s->tile_prefix.release(); s->tiles.release(); s->rank_pixel.release(); s->stack_spill.release(); s->chunk_start.release();
   s->stats_dev.release(); s->film.release(); s->packed.release(); s->sort_key.release(); s->order.release();
   if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->host_film) (void)hipHostFree(s->host_film);

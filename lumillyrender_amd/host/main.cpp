@@ -1,6 +1,6 @@
 // main.cpp -- lumilly_render: stand-alone driver, the counterpart of the reference binary
 // (src/main.rs:43-145): load the scene file, render it on every visible GPU (one host thread per
-// device, pixel tiles dealt round-robin, replicated scene), save png/hdr.
+// device, pixel tiles dealt diagonally (lr_host_tiles), replicated scene), save png/hdr.
 //
 //   lumilly_render <scene.toml> [--seed N] [--gpus N] [--spp N] [--out FILE] [--assets DIR]
 //

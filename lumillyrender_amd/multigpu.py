@@ -1,8 +1,8 @@
 """One process per GPU: shard the pixel tile queue over ranks, render, gather the film on rank 0.
 
 The path shards without any exchange step (pixels are independent jobs in the reference,
-main.rs:73-126): every rank holds the whole scene, renders the tiles `i % world == rank` of the
-row-major tile grid, and the film is assembled on the host -- the counterpart of the reference's channel drain
+main.rs:73-126): every rank holds the whole scene, renders the tiles lr_host_tiles deals to it (tile (i, j) of the 16-px
+tile grid -> rank (i + k j) mod world, k coprime with world: no stripes whatever the grid width), and the film is assembled on the host -- the counterpart of the reference's channel drain
 (main.rs:129-132): on one node every rank's lr_render writes its tiles straight into ONE film in POSIX shared
 memory (SharedFilm; lr_render only touches the pixels of the tiles it is given) and a barrier publishes it; across
 nodes rank 0 gathers each rank's packed tiles over gloo (gather_tiles).  No RCCL collective is on the data path.  RNG keys are (seed, pixel, sample), so the assembled film is bit-identical to a

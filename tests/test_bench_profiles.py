@@ -63,6 +63,20 @@ def test_library_build_id_is_the_content_hash_of_the_sources():
     assert device.build_id() == _tree_build_id(), "liblumilly_hip.so is stale against lumillyrender_amd/csrc (run make -C lumillyrender_amd/csrc)"
 
 
+def test_newest_profiles_were_taken_on_this_build():
+    """`roofline` mixes a live launch duration with the instruction counts of a COMMITTED counter pass, so the
+    pass must have been taken on the library that is being timed.  Every profiles/*_pmc_* / *_traffic_* file records the build id
+    of the library that was profiled (tools/profile_round.sh); the newest one of every BASELINE config must carry the id of the
+    sources in this tree -- a kernel edit without a new profile pass fails here, before a stale count reaches a bench line."""
+    b = _bench()
+    want_build = _tree_build_id()
+    for cfg, (scene, w, h, spp, *_rest) in b.CONFIGS.items():
+        for kind in ("pmc", "traffic"):
+            got = b.load_profile(kind, cfg, {"scene": scene, "width": w, "height": h, "spp": spp})
+            assert got is not None, (cfg, kind)
+            assert got[1].get("workload", {}).get("build") == want_build, (cfg, kind, os.path.basename(got[0]), got[1].get("workload", {}).get("build"), want_build)
+
+
 def test_bench_refuses_product_changing_environment(tmp_path):
     """A stale LR_* variable in the shell would silently change what bench.py measures: variables that change
     the product path are refused before anything touches the GPU, unless --allow-overrides; every LR_* variable is recorded."""

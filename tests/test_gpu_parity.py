@@ -295,8 +295,8 @@ def test_mesh_scene_parity(dev, oracle, name, integ):
     assert (st.samples, st.segments, st.shadow_rays) == (ost.samples, ost.segments, ost.shadow_rays)
     if name == "ibl-lens.toml":
         assert st.sky_fetches == ost.sky_fetches and st.sky_fetches > 0
-    scale = max(1.0, float(ref.max()))
-    assert linf(img, ref) < TOL * scale          # the IBL has ~1e3 texels: tolerance relative to the film's range
+    # the IBL has ~1e3 texels: a pixel brighter than 1 gets 1e-4 of ITS OWN value (per pixel: DESIGN section 2, round 5)
+    assert np.all(np.abs(img - ref) < TOL * np.maximum(1.0, np.abs(ref)))
     scene.close()
 
 
@@ -337,7 +337,7 @@ def test_ideal_refraction_parity(dev, oracle):
     assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
     assert np.array_equal(np.isnan(img), np.isnan(ref))
     ok = ~np.isnan(ref)
-    assert float(np.max(np.abs(img[ok] - ref[ok]))) < TOL * max(1.0, float(np.nanmax(ref)))
+    assert np.all(np.abs(img[ok] - ref[ok]) < TOL * np.maximum(1.0, np.abs(ref[ok])))
     scene.close()
 
 

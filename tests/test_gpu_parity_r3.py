@@ -142,7 +142,8 @@ def test_fused_pipeline_is_bit_identical_on_tree_scenes(dev, oracle, name, spp):
     s2 = dev.Scene(small)
     img = s2.render(small.render_params(spp=8, seed=5, flags=abi.LR_FLAG_FUSED))
     ref = oracle.render(small, small.render_params(spp=8, seed=5))
-    assert float(np.nanmax(np.abs(img - ref))) < TOL * max(1.0, float(np.nanmax(ref)))
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(img), np.isnan(ref)) and np.all(np.abs(img[fin] - ref[fin]) < TOL * np.maximum(1.0, np.abs(ref[fin])))
     scene.close(); s2.close()
 
 

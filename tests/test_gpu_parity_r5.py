@@ -172,7 +172,7 @@ def test_tile_deal_is_balanced_on_the_stated_films(dev, cfg):
                                                          ("mesh-box.toml", 0, ("default", "streaming")),
                                                          ("ibl-lens.toml", 1, ("default",))], ids=["cbox", "brdf", "mesh", "ibl"])
 def test_pixel_bands_give_the_same_film(dev, monkeypatch, scene_name, integ, flag_names):
-    """A call whose chunk sums exceed 3 GiB is rendered in bands of consecutive pixel ranks, two in flight on two streams
+    """A call whose chunk sums exceed 3 GiB is rendered in bands of consecutive pixel ranks, one launch each
     (Img::new is W x H whatever the spp, img.rs:13), and inside a launch the work items are dealt in sub-bands of 2^17 pixel ranks
     (the rays in flight stay within a strip of the film).  LR_BAND_PIX / LR_SUB_SHIFT force small bands and sub-bands on a small
     film: same film bits, same counters as the one-band render, in every pipeline -- including ragged last bands, a last sub-band
@@ -212,8 +212,8 @@ def test_pixel_bands_give_the_same_film(dev, monkeypatch, scene_name, integ, fla
 
 
 def test_config5_at_its_stated_size_stays_under_three_gigabytes(dev):
-    """the chunk sums of config 5 (2048 x 2048 at 8192 spp) were 17.2 GB in one buffer.  In pixel bands the
-    whole call -- scene, film, two bands of chunk sums -- adds less than 3 GB of device memory.  One frame at the stated size
+    """the chunk sums of config 5 (2048 x 2048 at 8192 spp) were 17.2 GB in one buffer.  In pixel bands (at most
+    2 GiB of sums each, one after the other) the whole call -- scene, film, chunk sums -- adds less than 3 GB of device memory.  One frame at the stated size
     (34 G samples, ~8 s): every sample rendered, film finite."""
     import ctypes as C
     if not gc.have_generated_assets():

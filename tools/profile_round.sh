@@ -12,7 +12,7 @@ CFGS=${*:-c2 c3 c4 c5}
 OUT=$PWD/gpurun_out/$TAG
 PROF=$OUT/profiles
 mkdir -p "$OUT" "$PROF" profiles
-REV=$(cat .git_rev 2>/dev/null || echo unknown)
+REV=$(cat .git_rev 2>/dev/null || echo unknown)           # written before the call: git rev-parse --short HEAD > .git_rev (the GPU box has no .git); `build` below is what ties a profile to a library
 BUILD=$(python3 -c "from lumillyrender_amd import device; print(device.build_id())")     # content hash of csrc/* + flags inside the library that is profiled
 export TMPDIR=/tmp
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"
