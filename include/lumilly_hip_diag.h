@@ -59,9 +59,9 @@ int lr_selftest_camera(LrScene* scene, int n, const int32_t* xy, const float* xi
  * out4[4*i..] = sampled point.xyz, pdf. */
 int lr_selftest_emission_sample(LrScene* scene, int n, const float* xi4, float* out4);
 
-/* The scene's 4-wide tree: out4 = {nodes, nodes stored WITHOUT distance culling (a sliver triangle -- sin of the angle at p0 below
- * 1/8 -- somewhere below them: DESIGN.md section 2; a heuristic threshold, this count is how much culling it gives up),
- * sliver triangles, worst-case traversal stack entries}. */
+/* The scene's 4-wide tree: out4 = {nodes, nodes whose distance-culling slack exceeds the distance itself (2 kappa >= 1: a
+ * wall-sized triangle somewhere below them, DESIGN.md section 2 -- this count is how much culling the error bound gives up),
+ * sliver triangles (sin of the angle at p0 below 1/8: statistics only), worst-case traversal stack entries}. */
 int lr_selftest_tree_info(LrScene* scene, int32_t* out4);
 
 /* How the scene's IBL map is stored in HBM: 4 = RGBE words (every texel of the caller's map is a Radiance value
