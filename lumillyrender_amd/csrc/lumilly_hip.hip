@@ -69,10 +69,11 @@ struct DevBuf {
 };
 
 constexpr double kSliverInvSin = 8.0;   // (statistics only since round 5: triangles with sin(angle at p0) < 1/8, lr_selftest_tree_info)
-constexpr double kCullSlack = 24.0;     // distance culling keeps kCullSlack eps |e1||e2| (|o - p0| + |t|) / 1e-3 of slack per child (Wide4Builder).  First-order
+constexpr double kCullSlack = 8.0;      // distance culling keeps kCullSlack eps |e1||e2| (|o - p0| + |t|) / 1e-3 of slack per child (Wide4Builder).  First-order
                                         // analysis of triangle.rs:69-100 in f32: |dN| <= 7.5 eps A |tv|, |d det| <= 7.5 eps A, t = N / det => |dt| <= 7.5 eps A (|tv| + |t|) / |det|
-                                        // + 2 eps |t|: a factor 3 of margin.  Measured (gpurun_out/r05j): 0 / 24 / 64 / 200 render config 4 at 4166 / 4086 / 4036 / 3912
-                                        // Msamples/s (round 4's sliver flag: 4101) and config 5 at 4099 / 4034 / 4003 / 3943 (4072)
+                                        // + 2 eps |t|; measured against float64 on 1.6 M accepted grazing hits: at most 1.9 (tests/test_oracle_properties.py).  Cost
+                                        // (interleaved, Msamples/s on config 4 | 5): 0: 4173 | 4074, 8: 4122 | 4026, 12: 4115 | 4018, 16: 4108 | 4019, 24: 4093 | 4014, 64: 4036 | 4003,
+                                        // 200: 3912 | 3943 (round 4's sliver flag: 4101 | 4072); the 22 residual seeds are clean from 4 upwards
 constexpr int kEventPool = 1024;      // timed launches per kernel type per render
 constexpr int kProfileStride = 2;     // time every 2nd iteration when LR_FLAG_PROFILE is set
 
@@ -147,7 +148,7 @@ struct Wide4Builder {
   // lies inside its primitive's box.  Moeller-Trumbore's distance t = (e2 . qv) / det carries an absolute error of up to
   // ~12 eps |e1||e2| (|o - p0| + |t|) / |det| and triangle.rs:75 accepts |det| down to an ABSOLUTE 1e-3, so a hit at grazing
   // incidence can be reported in front of its own (padded) box -- by 5 triangle sizes in round 4's fuzz.  Every node therefore
-  // carries kappa = kCullSlack (= 24) eps max|e1||e2| / 1e-3 over the triangles below it, and a child is culled only when it begins
+  // carries kappa = kCullSlack (= 8) eps max|e1||e2| / 1e-3 over the triangles below it, and a child is culled only when it begins
   // beyond   bound + kappa (2 t_far(child) + diagonal(node))   -- the error bound of any triangle inside that child, with
   // |o - p0| <= t_far + diagonal and |t| <= t_far.  For a well-conditioned mesh kappa is ~1e-2 (a few units of slack at the
   // scales of the BASELINE scenes: +2-3 % node visits); for a wall-sized triangle it is so large that nothing below the nodes that

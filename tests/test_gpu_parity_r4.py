@@ -300,7 +300,7 @@ def test_path_slots_bound_and_resident_request_that_does_not_fit(dev):
 
 
 def test_culling_slack_scope_is_tracked(dev):
-    """Round 5: a node carries kappa = 24 eps max|e1||e2| / 1e-3 over the triangles below it and a child is culled only beyond
+    """Round 5: a node carries kappa = 8 eps max|e1||e2| / 1e-3 over the triangles below it and a child is culled only beyond
     bound + kappa (2 t_far + diagonal) -- the error bound of Moeller-Trumbore's distance (triangle.rs:75 accepts |det| down to an
     absolute 1e-3).  Where 2 kappa >= 1 (a wall-sized triangle below) nothing is culled by distance, the reference's rule for that
     subtree (bvh.rs:131-141); its COST is tracked here: on the 100k-triangle mesh only the few nodes between the root and the

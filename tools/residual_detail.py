@@ -29,7 +29,7 @@ for seed in [int(a) for a in sys.argv[1:]]:
                 x = oo + t * dd; lo, hi = p.min(0), p.max(0)
                 outside = float(np.max(np.maximum(lo - x, x - hi)))
                 texact = (e2 @ np.cross(tv, e1)) / det
-                kappa = 24 * 2.0 ** -24 * A / 1e-3
+                kappa = 8 * 2.0 ** -24 * A / 1e-3
                 line += f" |e1||e2| {A:.4g} det64 {det:.4g} cos {cos:.3g} |tv| {np.linalg.norm(tv):.5g} t64 {texact:.6g} t32-t64 {t - texact:.4g} outside box by {outside:.4g}; kappa {kappa:.4g} -> slack at this distance {kappa * (np.linalg.norm(tv) + abs(t)):.4g}"
             print(line)
         scene.close()
