@@ -1871,11 +1871,13 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
     // from wave 0 up) tops the pool up here and the dispenser round trip hides behind the shading
     if (tid == RB - 1) pool_step(st, &pl, st.pool_low, st.pool_batch);   // sized by the host, see DevState
     uint32_t next_chunk = 0;
-    if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0, RB, LT>(sc, st, rp, lists + lpos(0) * RB, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1, RB, LT>(sc, st, rp, lists + lpos(1) * RB, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
-    if ((MTS & 4u) && (mt_mask & 4u)) resident_shade_list<2, RB, LT>(sc, st, rp, lists + lpos(2) * RB, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    // the dearest bodies first (GGX, Blinn-Phong, Phong, refraction), Lambert last: chunks are dealt round-robin across the lists, so the
+    // chunks beyond one per wave are then the cheap ones (round 5, BRDF row: 102.3 -> 100.4 ms per 2048 spp, +1.9 %; same film)
     if ((MTS & 8u) && (mt_mask & 8u)) resident_shade_list<3, RB, LT>(sc, st, rp, lists + lpos(3) * RB, s_cnt[3], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 4u) && (mt_mask & 4u)) resident_shade_list<2, RB, LT>(sc, st, rp, lists + lpos(2) * RB, s_cnt[2], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 2u) && (mt_mask & 2u)) resident_shade_list<1, RB, LT>(sc, st, rp, lists + lpos(1) * RB, s_cnt[1], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     if ((MTS & 16u) && (mt_mask & 16u)) resident_shade_list<4, RB, LT>(sc, st, rp, lists + lpos(4) * RB, s_cnt[4], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
+    if ((MTS & 1u) && (mt_mask & 1u)) resident_shade_list<0, RB, LT>(sc, st, rp, lists + lpos(0) * RB, s_cnt[0], shq, &s_cnt[6], finq, &s_cnt[7], wave, lane, &next_chunk);
     LR_TICK(3)
     __syncthreads();
     LR_TICK(5)
