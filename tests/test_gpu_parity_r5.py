@@ -251,3 +251,24 @@ def test_lateral_residual_is_pinned(dev):
     for tree, ray, prim, u, v, cos, outside in rows:
         assert outside > 0.0
         assert not (0.0 <= u <= 1.0 and v >= 0.0 and u + v <= 1.0), (tree, ray, prim, u, v)     # the exact line misses the triangle
+
+
+def test_more_than_two_to_the_32_work_items_in_one_call(dev):
+    """Round 4 refused a call with more than 2^32 - 2^24 work items (pixels x chunks): a 4096^2 film at 8192 spp.  The limit is
+    per pixel band now, and bands are cut by the chunk-sum budget, so the call goes through: 4096 x 3200 pixels x 336 chunks =
+    4.4 * 10^9 work items, 1.07 * 10^11 samples of the Cornell scene (~18 s), every sample rendered; a 16 x 16 tile of it rendered
+    on its own gives the same bits (the film does not depend on tiling or banding)."""
+    from lumillyrender_amd import abi
+    W, H, spp = 4096, 3200, 8192
+    desc = gc.load_scene("cbox-spheres.toml", None, W, H)
+    scene = dev.Scene(desc)
+    p = desc.render_params(spp=spp, seed=4, integrator=1)
+    img = scene.render(p)
+    st = scene.stats()
+    assert st.samples == W * H * spp
+    assert np.isfinite(img).all() and float(img.max()) > 0.1
+    tile = (abi.LrTile * 1)(); tile[0].x0, tile[0].y0, tile[0].w, tile[0].h = 2048, 1600, 16, 16
+    small = np.zeros((H, W, 3), dtype=np.float32)
+    scene.render(p, tile, 1, out=small)
+    assert np.array_equal(_bits(small[1600:1616, 2048:2064]), _bits(img[1600:1616, 2048:2064]))
+    scene.close()
