@@ -877,188 +877,187 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   if (n_pix > 0) hipLaunchKernelGGL(k_rank_table, dim3(grid_for((const void*)k_rank_table, s.n_cus, 0, n_pix)), dim3(kBlock), 0, st, dsc, ds);
   const DevState ds_all = ds;
   for (uint32_t band = 0; band < n_bands; ++band) {
-  const uint32_t r0 = band * band_pix, bn = std::min(band_pix, n_pix - r0);
-  hipStream_t bst = st;
-  ds = ds_all;
-  ds.n_pix = bn; ds.n_items = (uint32_t)((uint64_t)bn * n_chunks);
-  {
-    // sub-bands of 2^17 pixel ranks inside the launch (DevState): the rays in flight stay within one strip of the film.  Config 5:
-    // a rank's 1/8 share (524 k pixels spread over the whole film) 271 -> 257 ms, the whole frame -1.2 % (gpurun_out/r05g)
-    uint32_t shift = s.dev.n_flat > 0 ? 0u : kSubBandShift;           // flat scenes have no locality to win (14 primitives in the scalar cache) and pay for the longer decode: config 3 +1.1 %
-    if (const char* e = std::getenv("LR_SUB_SHIFT")) { int v = std::atoi(e); if (v == 0 || (v >= 6 && v <= 30)) shift = (uint32_t)v; }   // diagnostic
-    ds.sub_shift = 0; ds.sub_last_item0 = 0; ds.sub_last_rank0 = 0; ds.sub_last_pix = bn;
-    if (shift > 0 && shift < 31 && (bn >> shift) >= 2u) {
-      const uint32_t full = (bn >> shift) - 1u;                            // the last sub-band takes the remainder too
-      ds.sub_shift = shift; ds.sub_last_rank0 = full << shift; ds.sub_last_pix = bn - ds.sub_last_rank0;
-      ds.sub_last_item0 = (uint32_t)(((uint64_t)full * n_chunks) << shift);
-    }
-  }
-  ds.rank_pixel = s.rank_pixel.p + r0; ds.packed = want_packed ? s.packed.p + (size_t)r0 * 3 : nullptr;
-  if (fused || resident) ds.next_item = s.counters.p + 4 + band;
-  else if (band > 0) HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
-  if (ds.n_items > 0 && fused) {
-    const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
-    // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
-    ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
-    ds.pool_low = std::max<uint32_t>(1, ds.pool_batch / 2);
-    ds.pool_shift = 0;
-    while ((1ull << ds.pool_shift) < 2ull * n_waves) ++ds.pool_shift;     // 2 x the waves that draw from the dispenser
-    if (s.dev.n_flat == 0) {
-      dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
-      if (dsc.spill_depth > 0) {
-        s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
-        dsc.stack_spill = s.stack_spill.p;
+    const uint32_t r0 = band * band_pix, bn = std::min(band_pix, n_pix - r0);
+    ds = ds_all;
+    ds.n_pix = bn; ds.n_items = (uint32_t)((uint64_t)bn * n_chunks);
+    {
+      // sub-bands of 2^17 pixel ranks inside the launch (DevState): the rays in flight stay within one strip of the film.  Config 5:
+      // a rank's 1/8 share (524 k pixels spread over the whole film) 271 -> 257 ms, the whole frame -1.2 % (gpurun_out/r05g)
+      uint32_t shift = s.dev.n_flat > 0 ? 0u : kSubBandShift;           // flat scenes have no locality to win (14 primitives in the scalar cache) and pay for the longer decode: config 3 +1.1 %
+      if (const char* e = std::getenv("LR_SUB_SHIFT")) { int v = std::atoi(e); if (v == 0 || (v >= 6 && v <= 30)) shift = (uint32_t)v; }   // diagnostic
+      ds.sub_shift = 0; ds.sub_last_item0 = 0; ds.sub_last_rank0 = 0; ds.sub_last_pix = bn;
+      if (shift > 0 && shift < 31 && (bn >> shift) >= 2u) {
+        const uint32_t full = (bn >> shift) - 1u;                            // the last sub-band takes the remainder too
+        ds.sub_shift = shift; ds.sub_last_rank0 = full << shift; ds.sub_last_pix = bn - ds.sub_last_rank0;
+        ds.sub_last_item0 = (uint32_t)(((uint64_t)full * n_chunks) << shift);
       }
     }
-    const float4* flat_rows = (const float4*)s.flat.p;
-    void* args[4] = {&dsc, &ds, &dp, (void*)&flat_rows};                // k_path_tree takes the first three
-    L.run(LR_K_PATH, [&] { HIP_OK(hipLaunchKernel(fused_kernel, dim3(blocks), dim3(kBlock), args, fused_lds, bst)); }, bst);
-    S.iterations = 1;
-  } else if (ds.n_items > 0 && resident) {
-    uint32_t mt_mask = 0;
-    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
-    if (RB == 512) { ds.pool_batch *= 2; ds.pool_low *= 2; }
-    auto launch_resident = [&](auto kernel) {
-      HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
-      L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / RB), dim3(RB), resident_lds, bst, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); }, bst);
-    };
-    if (s.dev.n_flat > 0 && mt_mask == 1u) { if (RB == 512) launch_resident(k_resident<true, 1u, 512>); else launch_resident(k_resident<true, 1u, 256>); }   // flat, Lambert only
-    else if (s.dev.n_flat > 0) { if (RB == 512) launch_resident(k_resident<true, 31u, 512>); else launch_resident(k_resident<true, 31u, 256>); }
-    else launch_resident(k_resident<false, 31u, 256>);
-    S.iterations = 1;
-  } else if (ds.n_items > 0) {
-    // Two slot groups on two streams: the traversal kernels are latency- and divergence-bound, the shade kernels
-    // bandwidth-bound, so whenever the two groups are out of phase one's k_trace overlaps the other's k_shade
-    // (+10 % on the mesh configs, free-running; chaining the traces with events so that they alternate strictly,
-    // or halving the grids, was slower).  The groups share the item dispenser, the chunk sums and the statistics;
-    // everything indexed by slot or segment is split.  Small jobs and the counting mode keep one group.
-    // k_shade_all is instantiated for the material sets of the BASELINE scenes (Lambert only; Lambert + GGX) and for "anything"
-    uint32_t present_bsdf = 0;
-    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) present_bsdf |= 1u << k;
-    const int dense_variant = (present_bsdf | 1u) == 1u ? 0 : ((present_bsdf | 9u) == 9u ? 1 : 2);
-    const void* kdense = dense_variant == 0 ? (const void*)k_shade_all<1u> : (dense_variant == 1 ? (const void*)k_shade_all<9u> : (const void*)k_shade_all<31u>);
-    constexpr int kMaxGroups = 3;
-    // two slot groups on two streams; three when an iteration is only trace + shade (no shadow stage): measured +4 % on the
-    // 100k-triangle pt scene, -3 % on the pt-direct one
-    const bool has_shadow_stage = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
-    int G = (!count && n_seg >= 64) ? ((dense_shade && !has_shadow_stage && n_seg >= 96) ? 3 : 2) : 1;
-    if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
-    for (int g = 1; g < G; ++g) if (!s.gstream[g - 1]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[g - 1], hipStreamNonBlocking));
-    if (G > 1 && !s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    struct Group {
-      DevState ds; DevScene dsc; hipStream_t st; uint32_t n_slots, n_seg, spb; int g_trace, g_shadow, g_gen, g_shade[kNumShadeQueues], g_dense;
-    } grp[kMaxGroups];
-    uint32_t spill_per_group = 0;
-    for (int g = 0; g < G; ++g) {
-      Group& q = grp[g];
-      const uint32_t base_seg = (uint32_t)((uint64_t)n_seg * g / G);
-      q.n_seg = (uint32_t)((uint64_t)n_seg * (g + 1) / G) - base_seg;
-      q.n_slots = q.n_seg * kSeg;
-      const size_t base = (size_t)base_seg * kSeg;
-      q.st = g == 0 ? st : s.gstream[g - 1];
-      q.ds = ds;
-      q.ds.ray_o += base; q.ds.ray_d += base; q.ds.hit += base; q.ds.thr += base; q.ds.rad += base; q.ds.acc += base;
-      q.ds.sh_d += base; q.ds.sh_w += base;
-      if (!dense_shade) q.ds.q_shade += (size_t)kNumShadeQueues * base;
-      q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
-      q.ds.q_shadow += shadow_lists * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
-      q.ds.pool += base_seg;
-      if (q.ds.order) { q.ds.order += base; q.ds.sort_key += base; }
-      q.ds.n_retired = s.counters.p + 1 + g;
-      q.ds.n_slots = q.n_slots; q.ds.n_seg = q.n_seg;
-      q.g_trace = grid_for(ktrace, s.n_cus, lds, q.n_seg * kBlock);
-      q.g_shadow = grid_for(kshadow, s.n_cus, lds, q.n_seg * kBlock);
-      uint32_t max_group = kMaxGroup;
-      if (const char* e = std::getenv("LR_MAXGROUP")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxGroup) max_group = (uint32_t)v; }   // diagnostic: shorter passes / smaller sort windows
-      q.spb = std::min<uint32_t>(max_group, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
-      q.ds.trace_spb = q.spb;
-      q.g_gen = grid_for((const void*)k_generate, s.n_cus, 0, q.n_seg * kBlock);
-      const uint32_t n_ranges = (q.n_seg + q.spb - 1) / q.spb;                           // k_shade: one workgroup per trace range
-      q.g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, shade_lds, n_ranges * kBlock);
-      q.g_dense = grid_for(kdense, s.n_cus, 0, n_ranges * kBlock);
-      q.dsc = dsc;
-      spill_per_group = std::max<uint32_t>(spill_per_group, (uint32_t)std::max(q.g_trace, q.g_shadow));
-    }
-    if (dsc.spill_depth > 0) {
-      const size_t per = (size_t)spill_per_group * dsc.spill_depth * kBlock;
-      s.stack_spill.ensure(per * G);
-      for (int g = 0; g < G; ++g) grp[g].dsc.stack_spill = s.stack_spill.p + per * g;
-    }
-    if (G > 1) { HIP_OK(hipEventRecord(s.grp_ev[0], st)); for (int g = 1; g < G; ++g) HIP_OK(hipStreamWaitEvent(s.gstream[g - 1], s.grp_ev[0], 0)); }   // uploads, memsets, rank table
-    for (int g = 0; g < G; ++g) {
-      Group& q = grp[g];
-      L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(q.g_gen), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
-    }
-    const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
-    const int kCheck = 8;
-    int batch = 0;
-    uint32_t mt_mask = 0;
-    for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
-    bool done = false;
-    // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
-    // length statistically, this bounds the loop against a logic error
-    const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
-    auto retired_all = [&](const uint32_t* per_group) {
-      for (int g = 0; g < G; ++g) if (per_group[g] < grp[g].n_slots) return false;
-      return true;
-    };
-    while (!done) {
-      for (int k = 0; k < kCheck; ++k) {
-        for (int g = 0; g < G; ++g) {
-          Group& q = grp[g];
-          auto launch_trace = [&](auto kernel) {
-            L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
-          };
-          if (count) { if (sort_rays) launch_trace(k_trace<true, true>); else launch_trace(k_trace<true, false>); }
-          else { if (sort_rays) launch_trace(k_trace<false, true>); else launch_trace(k_trace<false, false>); }
-          if (dense_shade) {
-            L.run(LR_K_SHADE, [&] {
-              if (dense_variant == 0) hipLaunchKernelGGL(k_shade_all<1u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
-              else if (dense_variant == 1) hipLaunchKernelGGL(k_shade_all<9u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
-              else hipLaunchKernelGGL(k_shade_all<31u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
-            }, q.st);
-          } else {
-          if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(q.g_shade[0]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(q.g_shade[1]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(q.g_shade[2]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(q.g_shade[3]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(q.g_shade[4]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(q.g_shade[5]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
-          }
-          if (nee) {
-            auto launch_shadow = [&](auto kernel) {
-              L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, dense_shade ? 1u : mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
-            };
-            if (count) { if (sort_rays) launch_shadow(k_shadow<true, true>); else launch_shadow(k_shadow<true, false>); }
-            else { if (sort_rays) launch_shadow(k_shadow<false, true>); else launch_shadow(k_shadow<false, false>); }
-          }
+    ds.rank_pixel = s.rank_pixel.p + r0; ds.packed = want_packed ? s.packed.p + (size_t)r0 * 3 : nullptr;
+    if (fused || resident) ds.next_item = s.counters.p + 4 + band;
+    else if (band > 0) HIP_OK(hipMemsetAsync(s.counters.p, 0, 4 * sizeof(uint32_t), st));
+    if (ds.n_items > 0 && fused) {
+      const uint32_t blocks = n_slots / kBlock, n_waves = blocks * (kBlock / 64);
+      // a wave reserves pool_batch work items per trip to the dispenser, one trip ahead of need
+      ds.pool_batch = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, n_items64 / (4ull * n_waves)));
+      ds.pool_low = std::max<uint32_t>(1, ds.pool_batch / 2);
+      ds.pool_shift = 0;
+      while ((1ull << ds.pool_shift) < 2ull * n_waves) ++ds.pool_shift;     // 2 x the waves that draw from the dispenser
+      if (s.dev.n_flat == 0) {
+        dsc.stack_lds = fused_stack; dsc.spill_depth = s.stack_depth - fused_stack; dsc.stack_spill = nullptr;
+        if (dsc.spill_depth > 0) {
+          s.stack_spill.ensure((size_t)blocks * dsc.spill_depth * kBlock);
+          dsc.stack_spill = s.stack_spill.p;
         }
-        L.iter++; S.iterations++;
       }
-      // poll the retired-slot counters one batch behind so the queue never drains
-      for (int g = 1; g < G; ++g) { HIP_OK(hipEventRecord(s.grp_ev[g], s.gstream[g - 1])); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[g], 0)); }
-      HIP_OK(hipMemcpyAsync(&s.pinned[(batch & 1) * 4], s.counters.p + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      HIP_OK(hipEventRecord(s.poll_ev[batch & 1], st));
-      if (batch > 0) {
-        HIP_OK(hipEventSynchronize(s.poll_ev[(batch - 1) & 1]));
-        if (retired_all(&s.pinned[((batch - 1) & 1) * 4])) done = true;
+      const float4* flat_rows = (const float4*)s.flat.p;
+      void* args[4] = {&dsc, &ds, &dp, (void*)&flat_rows};                // k_path_tree takes the first three
+      L.run(LR_K_PATH, [&] { HIP_OK(hipLaunchKernel(fused_kernel, dim3(blocks), dim3(kBlock), args, fused_lds, st)); });
+      S.iterations = 1;
+    } else if (ds.n_items > 0 && resident) {
+      uint32_t mt_mask = 0;
+      for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+      if (RB == 512) { ds.pool_batch *= 2; ds.pool_low *= 2; }
+      auto launch_resident = [&](auto kernel) {
+        HIP_OK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds));
+        L.run(LR_K_RESIDENT, [&] { hipLaunchKernelGGL(kernel, dim3(n_slots / RB), dim3(RB), resident_lds, st, dsc, ds, dp, mt_mask, (const float4*)s.flat.p); });
+      };
+      if (s.dev.n_flat > 0 && mt_mask == 1u) { if (RB == 512) launch_resident(k_resident<true, 1u, 512>); else launch_resident(k_resident<true, 1u, 256>); }   // flat, Lambert only
+      else if (s.dev.n_flat > 0) { if (RB == 512) launch_resident(k_resident<true, 31u, 512>); else launch_resident(k_resident<true, 31u, 256>); }
+      else launch_resident(k_resident<false, 31u, 256>);
+      S.iterations = 1;
+    } else if (ds.n_items > 0) {
+      // Two slot groups on two streams: the traversal kernels are latency- and divergence-bound, the shade kernels
+      // bandwidth-bound, so whenever the two groups are out of phase one's k_trace overlaps the other's k_shade
+      // (+10 % on the mesh configs, free-running; chaining the traces with events so that they alternate strictly,
+      // or halving the grids, was slower).  The groups share the item dispenser, the chunk sums and the statistics;
+      // everything indexed by slot or segment is split.  Small jobs and the counting mode keep one group.
+      // k_shade_all is instantiated for the material sets of the BASELINE scenes (Lambert only; Lambert + GGX) and for "anything"
+      uint32_t present_bsdf = 0;
+      for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) present_bsdf |= 1u << k;
+      const int dense_variant = (present_bsdf | 1u) == 1u ? 0 : ((present_bsdf | 9u) == 9u ? 1 : 2);
+      const void* kdense = dense_variant == 0 ? (const void*)k_shade_all<1u> : (dense_variant == 1 ? (const void*)k_shade_all<9u> : (const void*)k_shade_all<31u>);
+      constexpr int kMaxGroups = 3;
+      // two slot groups on two streams; three when an iteration is only trace + shade (no shadow stage): measured +4 % on the
+      // 100k-triangle pt scene, -3 % on the pt-direct one
+      const bool has_shadow_stage = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
+      int G = (!count && n_seg >= 64) ? ((dense_shade && !has_shadow_stage && n_seg >= 96) ? 3 : 2) : 1;
+      if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
+      for (int g = 1; g < G; ++g) if (!s.gstream[g - 1]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[g - 1], hipStreamNonBlocking));
+      if (G > 1 && !s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      struct Group {
+        DevState ds; DevScene dsc; hipStream_t st; uint32_t n_slots, n_seg, spb; int g_trace, g_shadow, g_gen, g_shade[kNumShadeQueues], g_dense;
+      } grp[kMaxGroups];
+      uint32_t spill_per_group = 0;
+      for (int g = 0; g < G; ++g) {
+        Group& q = grp[g];
+        const uint32_t base_seg = (uint32_t)((uint64_t)n_seg * g / G);
+        q.n_seg = (uint32_t)((uint64_t)n_seg * (g + 1) / G) - base_seg;
+        q.n_slots = q.n_seg * kSeg;
+        const size_t base = (size_t)base_seg * kSeg;
+        q.st = g == 0 ? st : s.gstream[g - 1];
+        q.ds = ds;
+        q.ds.ray_o += base; q.ds.ray_d += base; q.ds.hit += base; q.ds.thr += base; q.ds.rad += base; q.ds.acc += base;
+        q.ds.sh_d += base; q.ds.sh_w += base;
+        if (!dense_shade) q.ds.q_shade += (size_t)kNumShadeQueues * base;
+        q.ds.c_shade += (size_t)kNumShadeQueues * base_seg;
+        q.ds.q_shadow += shadow_lists * base; q.ds.c_shadow += (size_t)(kNumShadeQueues - 1) * base_seg;
+        q.ds.pool += base_seg;
+        if (q.ds.order) { q.ds.order += base; q.ds.sort_key += base; }
+        q.ds.n_retired = s.counters.p + 1 + g;
+        q.ds.n_slots = q.n_slots; q.ds.n_seg = q.n_seg;
+        q.g_trace = grid_for(ktrace, s.n_cus, lds, q.n_seg * kBlock);
+        q.g_shadow = grid_for(kshadow, s.n_cus, lds, q.n_seg * kBlock);
+        uint32_t max_group = kMaxGroup;
+        if (const char* e = std::getenv("LR_MAXGROUP")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxGroup) max_group = (uint32_t)v; }   // diagnostic: shorter passes / smaller sort windows
+        q.spb = std::min<uint32_t>(max_group, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
+        q.ds.trace_spb = q.spb;
+        q.g_gen = grid_for((const void*)k_generate, s.n_cus, 0, q.n_seg * kBlock);
+        const uint32_t n_ranges = (q.n_seg + q.spb - 1) / q.spb;                           // k_shade: one workgroup per trace range
+        q.g_shade[0] = grid_for((const void*)k_shade<0>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_shade[1] = grid_for((const void*)k_shade<1>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_shade[2] = grid_for((const void*)k_shade<2>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_shade[3] = grid_for((const void*)k_shade<3>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_shade[4] = grid_for((const void*)k_shade<4>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_shade[5] = grid_for((const void*)k_shade<5>, s.n_cus, shade_lds, n_ranges * kBlock);
+        q.g_dense = grid_for(kdense, s.n_cus, 0, n_ranges * kBlock);
+        q.dsc = dsc;
+        spill_per_group = std::max<uint32_t>(spill_per_group, (uint32_t)std::max(q.g_trace, q.g_shadow));
       }
-      ++batch;
-      if (S.iterations > max_iter) fail(LR_EDEVICE, "render loop did not terminate (internal error)");
+      if (dsc.spill_depth > 0) {
+        const size_t per = (size_t)spill_per_group * dsc.spill_depth * kBlock;
+        s.stack_spill.ensure(per * G);
+        for (int g = 0; g < G; ++g) grp[g].dsc.stack_spill = s.stack_spill.p + per * g;
+      }
+      if (G > 1) { HIP_OK(hipEventRecord(s.grp_ev[0], st)); for (int g = 1; g < G; ++g) HIP_OK(hipStreamWaitEvent(s.gstream[g - 1], s.grp_ev[0], 0)); }   // uploads, memsets, rank table
+      for (int g = 0; g < G; ++g) {
+        Group& q = grp[g];
+        L.run(LR_K_GENERATE, [&] { hipLaunchKernelGGL(k_generate, dim3(q.g_gen), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp); }, q.st);
+      }
+      const bool nee = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
+      const int kCheck = 8;
+      int batch = 0;
+      uint32_t mt_mask = 0;
+      for (int k = 0; k < kNumShadeQueues - 1; ++k) if (s.mat_present[k]) mt_mask |= 1u << k;
+      bool done = false;
+      // hard stop: every iteration advances every live path by one vertex; depth_limit bounds path
+      // length statistically, this bounds the loop against a logic error
+      const uint64_t max_iter = ((uint64_t)n_items * chunk_spp / n_slots + 64) * 4096ull;
+      auto retired_all = [&](const uint32_t* per_group) {
+        for (int g = 0; g < G; ++g) if (per_group[g] < grp[g].n_slots) return false;
+        return true;
+      };
+      while (!done) {
+        for (int k = 0; k < kCheck; ++k) {
+          for (int g = 0; g < G; ++g) {
+            Group& q = grp[g];
+            auto launch_trace = [&](auto kernel) {
+              L.run(LR_K_TRACE, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_trace), dim3(kBlock), lds, q.st, q.dsc, q.ds, (const float4*)s.flat.p, q.spb); }, q.st);
+            };
+            if (count) { if (sort_rays) launch_trace(k_trace<true, true>); else launch_trace(k_trace<true, false>); }
+            else { if (sort_rays) launch_trace(k_trace<false, true>); else launch_trace(k_trace<false, false>); }
+            if (dense_shade) {
+              L.run(LR_K_SHADE, [&] {
+                if (dense_variant == 0) hipLaunchKernelGGL(k_shade_all<1u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
+                else if (dense_variant == 1) hipLaunchKernelGGL(k_shade_all<9u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
+                else hipLaunchKernelGGL(k_shade_all<31u>, dim3(q.g_dense), dim3(kBlock), 0, q.st, q.dsc, q.ds, dp);
+              }, q.st);
+            } else {
+            if (s.mat_present[0]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<0>, dim3(q.g_shade[0]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            if (s.mat_present[1]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<1>, dim3(q.g_shade[1]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            if (s.mat_present[2]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<2>, dim3(q.g_shade[2]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            if (s.mat_present[3]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<3>, dim3(q.g_shade[3]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            if (s.mat_present[4]) L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<4>, dim3(q.g_shade[4]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            L.run(LR_K_SHADE, [&] { hipLaunchKernelGGL(k_shade<5>, dim3(q.g_shade[5]), dim3(kBlock), shade_lds, q.st, q.dsc, q.ds, dp); }, q.st);
+            }
+            if (nee) {
+              auto launch_shadow = [&](auto kernel) {
+                L.run(LR_K_SHADOW, [&] { hipLaunchKernelGGL(kernel, dim3(q.g_shadow), dim3(kBlock), lds, q.st, q.dsc, q.ds, dense_shade ? 1u : mt_mask, (const float4*)s.flat.p, q.spb); }, q.st);
+              };
+              if (count) { if (sort_rays) launch_shadow(k_shadow<true, true>); else launch_shadow(k_shadow<true, false>); }
+              else { if (sort_rays) launch_shadow(k_shadow<false, true>); else launch_shadow(k_shadow<false, false>); }
+            }
+          }
+          L.iter++; S.iterations++;
+        }
+        // poll the retired-slot counters one batch behind so the queue never drains
+        for (int g = 1; g < G; ++g) { HIP_OK(hipEventRecord(s.grp_ev[g], s.gstream[g - 1])); HIP_OK(hipStreamWaitEvent(st, s.grp_ev[g], 0)); }
+        HIP_OK(hipMemcpyAsync(&s.pinned[(batch & 1) * 4], s.counters.p + 1, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipEventRecord(s.poll_ev[batch & 1], st));
+        if (batch > 0) {
+          HIP_OK(hipEventSynchronize(s.poll_ev[(batch - 1) & 1]));
+          if (retired_all(&s.pinned[((batch - 1) & 1) * 4])) done = true;
+        }
+        ++batch;
+        if (S.iterations > max_iter) fail(LR_EDEVICE, "render loop did not terminate (internal error)");
+      }
+      for (int g = 1; g < G; ++g) HIP_OK(hipStreamSynchronize(s.gstream[g - 1]));
+      HIP_OK(hipStreamSynchronize(st));
+      if (!retired_all(&s.pinned[((batch - 1) & 1) * 4])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
     }
-    for (int g = 1; g < G; ++g) HIP_OK(hipStreamSynchronize(s.gstream[g - 1]));
-    HIP_OK(hipStreamSynchronize(st));
-    if (!retired_all(&s.pinned[((batch - 1) & 1) * 4])) fail(LR_EDEVICE, "render loop ended with live paths (internal error)");
-  }
-  if (bn > 0) {
-    int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, bn);
-    L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, bst, dsc, ds, dp); }, bst);
-  }
+    if (bn > 0) {
+      int g_res = grid_for((const void*)k_resolve, s.n_cus, 0, bn);
+      L.run(LR_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(kBlock), 0, st, dsc, ds, dp); });
+    }
   }   // bands
   HIP_OK(hipEventRecord(s.t_end, st));
   unsigned long long* hshards = (unsigned long long*)(s.pinned + 8);

@@ -29,7 +29,9 @@ for seed in [int(a) for a in sys.argv[1:]]:
                 x = oo + t * dd; lo, hi = p.min(0), p.max(0)
                 outside = float(np.max(np.maximum(lo - x, x - hi)))
                 texact = (e2 @ np.cross(tv, e1)) / det
+                u64, v64 = (tv @ pv) / det, (dd @ np.cross(tv, e1)) / det
+                lateral = not (0.0 <= u64 <= 1.0 and v64 >= 0.0 and u64 + v64 <= 1.0)
                 kappa = 8 * 2.0 ** -24 * A / 1e-3
-                line += f" |e1||e2| {A:.4g} det64 {det:.4g} cos {cos:.3g} |tv| {np.linalg.norm(tv):.5g} t64 {texact:.6g} t32-t64 {t - texact:.4g} outside box by {outside:.4g}; kappa {kappa:.4g} -> slack at this distance {kappa * (np.linalg.norm(tv) + abs(t)):.4g}"
+                line += f" |e1||e2| {A:.4g} det64 {det:.4g} cos {cos:.3g} |tv| {np.linalg.norm(tv):.5g} t64 {texact:.6g} t32-t64 {t - texact:.4g} outside box by {outside:.4g}; kappa {kappa:.4g} -> slack at this distance {kappa * (np.linalg.norm(tv) + abs(t)):.4g}; float64 barycentrics ({u64:.4f}, {v64:.4f}) -> {'LATERAL: the exact line misses the triangle' if lateral else 'along the ray: the exact line meets the triangle'}"
             print(line)
         scene.close()
