@@ -59,6 +59,7 @@ def _load():
     lib.lr_host_tile_rank.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.lr_host_tile_stride.argtypes = [C.c_int]
     lib.lr_host_default_tile.argtypes = []
+    lib.lr_host_shm_barrier.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.lr_host_sizeof.argtypes = [C.c_char_p]
     lib.lr_host_sizeof.restype = C.c_size_t
     return lib
@@ -156,6 +157,11 @@ class Description:
         p.path_slots = path_slots
         p.flags = flags
         return p
+
+
+def shm_barrier(state_address, world, timeout_s=120.0):
+    """Barrier of `world` processes on two uint32 words of shared memory at `state_address` (lumilly_host.h)."""
+    _check(lib().lr_host_shm_barrier(C.c_void_p(state_address), int(world), float(timeout_s)))
 
 
 def default_tile():

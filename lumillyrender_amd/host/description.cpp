@@ -3,7 +3,9 @@
 // instance order, OBJ faces become triangles in file order, spheres take the transformed origin
 // and an UNSCALED radius, emission binds to objects by light.object == object.name.
 #include "host_internal.h"
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -373,6 +375,34 @@ int lr_host_tiles(int width, int height, int tile, int rank, int world, LrTile* 
       ++count;
     }
   return count;
+}
+
+// Barrier of `world` processes on two words of shared memory (the film every rank of a node maps: multigpu.SharedFilm):
+// state[0] = arrivals of the current round, state[1] = round number.  Sense-reversing: the last arrival resets the count and
+// advances the round, the others spin on the round (pause, then yield, then sleep 50 us) until it moves or `timeout_s` runs out.
+// Sequentially consistent atomics: everything a rank wrote into the film before it arrived is visible to every rank that leaves.
+int lr_host_shm_barrier(uint32_t* state, int world, double timeout_s) {
+  if (!state || world <= 0) { set_last_error("bad barrier arguments"); return LR_EINVAL; }
+  if (world == 1) return LR_OK;
+  const uint32_t round = __atomic_load_n(&state[1], __ATOMIC_SEQ_CST);
+  if (__atomic_add_fetch(&state[0], 1u, __ATOMIC_SEQ_CST) == (uint32_t)world) {
+    __atomic_store_n(&state[0], 0u, __ATOMIC_SEQ_CST);
+    __atomic_add_fetch(&state[1], 1u, __ATOMIC_SEQ_CST);
+    return LR_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0;; ++spins) {
+    if (__atomic_load_n(&state[1], __ATOMIC_SEQ_CST) != round) return LR_OK;
+    if (spins < 2000) __builtin_ia32_pause();
+    else if (spins < 20000) std::this_thread::yield();
+    else {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+        set_last_error("shared-memory barrier timed out (a rank of the node did not arrive)");
+        return LR_EDEVICE;
+      }
+    }
+  }
 }
 
 size_t lr_host_sizeof(const char* name) {

@@ -91,6 +91,9 @@ def gather_tiles(film, width, height, tile, dist=None, dst=0, group=None):
     return film
 
 
+_BARRIER_WORDS = 16          # floats appended to the shared film file: 64 bytes, of which lr_host_shm_barrier uses two uint32 words
+
+
 class SharedFilm:
     """The film all ranks of one node render into.  `array` is an (H, W, 3) float32 view of a file in /dev/shm mapped by
     every rank; `collect()` makes the ranks' tiles visible on rank `dst` (a barrier).  Ranks on different hosts (or no
@@ -114,16 +117,21 @@ class SharedFilm:
             dist.all_gather_object(hosts, socket.gethostname(), group=group)
             self.shared = len(set(hosts)) == 1 and os.path.isdir("/dev/shm")
         if self.shared:
+            n_film = height * width * 3
+            n_film += (-n_film) % 16                                  # the barrier words start on a 64-byte boundary
             box = [None]
             if rank == dst:
                 self.path = f"/dev/shm/lumilly_film_{os.getpid()}_{time.time_ns()}.f32"
-                self.array = np.memmap(self.path, dtype=np.float32, mode="w+", shape=(height, width, 3))
+                self._map = np.memmap(self.path, dtype=np.float32, mode="w+", shape=(n_film + _BARRIER_WORDS,))     # zero-filled: film + barrier state
                 box[0] = self.path
             src = dist.get_global_rank(group, dst) if group is not None else dst
             dist.broadcast_object_list(box, src=src, group=group)
             if rank != dst:
                 self.path = box[0]
-                self.array = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+                self._map = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(n_film + _BARRIER_WORDS,))
+            self.array = self._map[:n_film].reshape(height, width, 3)
+            self._state = self._map[n_film:].ctypes.data             # two uint32 words on a cache line of their own (lr_host_shm_barrier)
+            self._world = world
             self.name = self.path
             self._owner = rank == dst
             dist.barrier(group=group)                                 # every rank holds its mapping ...
@@ -135,10 +143,15 @@ class SharedFilm:
             self.array = np.zeros((height, width, 3), dtype=np.float32)
             self._owner = False
 
+    def _barrier(self):
+        # the ranks of one node meet on two words of the shared film file itself (lr_host_shm_barrier): a gloo barrier of 8 processes
+        # takes 0.3-0.6 ms, 2-3 % of a rank's 22-ms share of the headline frame; this one takes microseconds
+        host.shm_barrier(self._state, self._world)
+
     def collect(self):
         """After every rank rendered its tiles into `array`: the complete film is readable on dst."""
         if self.shared:
-            self.dist.barrier(group=self.group)
+            self._barrier()
         else:
             gather_tiles(self.array, self.width, self.height, self.tile, self.dist, dst=self.dst, group=self.group)
         return self.array
@@ -146,11 +159,11 @@ class SharedFilm:
     def release(self):
         """dst has consumed the frame: the ranks may render the next one into the film."""
         if self.shared:
-            self.dist.barrier(group=self.group)
+            self._barrier()
 
     def close(self):
         if self.shared:
             self.dist.barrier(group=self.group)
-            arr, self.array = self.array, None
+            arr, self.array, self._map = self.array, None, None
             del arr
             self.shared = False

@@ -3,6 +3,7 @@ replaced by the oracle here (tests may use it); what is under test is the tile s
 per-rank films and the host gather: the assembled film must equal a single-rank render bit for bit."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -171,3 +172,31 @@ def test_gather_on_a_subgroup(tmp_path):
     ref = oracle.render(desc, desc.render_params(spp=SPP, seed=4), threads=2)
     got = np.load(out_path)
     assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
+def _shm_barrier_worker(rank, world, path, rounds):
+    from lumillyrender_amd import host
+    m = np.memmap(path, dtype=np.uint32, mode="r+", shape=(64,))
+    state = m[48:].ctypes.data                                      # two words on a cache line of their own
+    for it in range(1, rounds + 1):
+        m[rank] = it                                                 # plain store before arriving ...
+        host.shm_barrier(state, world, 30.0)
+        assert all(int(m[r]) >= it for r in range(world)), (rank, it, [int(m[r]) for r in range(world)])   # ... is visible to everyone who leaves
+        host.shm_barrier(state, world, 30.0)                         # (nobody overwrites its slot before everyone has looked)
+
+
+def test_shared_memory_barrier(tmp_path):
+    """lr_host_shm_barrier (the per-frame barrier of multigpu.SharedFilm on one node): 4 processes, 2000 rounds, every store made
+    before a rank arrives is seen by every rank that leaves; a barrier the others never reach returns an error after its timeout
+    instead of spinning for ever."""
+    from lumillyrender_amd import host
+    path = tmp_path / "barrier.u32"
+    np.zeros(64, dtype=np.uint32).tofile(path)
+    mp.spawn(_shm_barrier_worker, args=(4, str(path), 2000), nprocs=4, join=True)
+    m = np.memmap(path, dtype=np.uint32, mode="r+", shape=(64,))
+    assert int(m[48]) == 0 and int(m[49]) == 4000                   # count back at zero, 2 x 2000 rounds
+    t0 = time.time()
+    with pytest.raises(host.LumillyError):
+        host.shm_barrier(m[48:].ctypes.data, 2, 0.2)                 # world 2, one arrival
+    assert time.time() - t0 < 5.0
+    host.shm_barrier(m[48:].ctypes.data, 1, 0.2)                     # world 1: nothing to wait for
