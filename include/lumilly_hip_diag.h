@@ -34,10 +34,17 @@ int lr_selftest_rng(int device, uint32_t seed, const uint32_t* pixel, const uint
  * prim_out[i] = primitive index or -1, t_out[i] = distance (0 on a miss).  Replaces bvh.rs:130-141 for a batch. */
 int lr_selftest_intersect(LrScene* scene, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out);
 
-/* The DEFINITION of the closest hit on the device: every ray against EVERY primitive (no tree, no boxes), minimum
- * distance, ties to the lowest primitive index -- bvh.rs:131-141's "min over all candidates" with the candidate set
- * widened to the whole scene.  Same primitive tests as the render path.  O(n * n_prims). */
+/* Closest hit of n rays through the scene's traversal path (flat loop or 4-wide tree, as lr_render would choose) --
+ * see above -- is checked against two brute-force forms on the device, both O(n * n_prims), same primitive tests as
+ * the render path, ties to the lowest primitive index:
+ *   lr_selftest_brute_own_box  the DEFINITION of the render path's closest hit (bvh.rs:20-25 + 131-141): every ray
+ *                              against every primitive whose OWN exact box passes aabb.rs:74-92 (the literal slab test,
+ *                              evaluated per primitive, no tree, no shortcut);
+ *   lr_selftest_brute          the candidate set widened to EVERY primitive, no box at all (what rounds 1-5 defined
+ *                              the closest hit by; differs from the reference where a leaf's own box rejects a ray its
+ *                              primitive test accepts). */
 int lr_selftest_brute(LrScene* scene, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out);
+int lr_selftest_brute_own_box(LrScene* scene, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out);
 
 /* Emitter pick of objects.rs:37-51 on the device: for n uniform draws xi in [0,1), k_out[i] = index (into the scene's
  * emitter list, instance order) of the emitter chosen by roulette = total_area * xi[i]. */

@@ -17,6 +17,10 @@
 //   shade   4 x float4 per primitive id (64 B, one cache line, the four loads of a vertex go out together):
 //             {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
 //             {color.rgb, type} {emission.rgb, weight} {param0..2, -}    = the primitive's material, denormalised
+//   pbox    2 x float4 per primitive id: the primitive's OWN exact box {min.xyz, -} {max.xyz, -} as triangle.rs:102-118 /
+//           sphere.rs:31-38 compute it.  bvh.rs:20-25 makes a primitive a candidate only if aabb.rs:74-92 passes on it:
+//           read once per query for the primitive that decides it (lr_kernels.h own_box_surely), and per primitive by the
+//           literal re-trace of the few undecided rays
 //   emit    3 x float4 per emitter (objects.rs:19-24, instance order):
 //             {p0|c .xyz, type} {p1.xyz | r, pdf} {p2.xyz, cumulative area}
 //   texels  float4 per IBL texel (rgb, -); or, when every texel of the map is a Radiance RGBE value (c * 2^(e - 136), the
@@ -64,6 +68,7 @@ struct DevScene {
   const float4* nodes;
   const float4* prims;
   const float4* shade;
+  const float4* pbox;                  // 2 rows per primitive id: its own exact box {min.xyz, -} {max.xyz, -} (bvh.rs:20-25 decides with it)
   const float4* emit;
   const float4* texels;
   const uint32_t* texels_rgbe;         // non-null: the map as RGBE words r | g << 8 | b << 16 | e << 24 (e >= 10: every value normal or zero), texels unused

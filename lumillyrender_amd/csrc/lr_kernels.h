@@ -116,11 +116,74 @@ LR_DEV bool sphere_test(V3 c, float r2, V3 o, V3 d, float* t_out) {
 }
 
 // ------------------------------------------------------------------------------------------
-// BVH traversal.  Closest hit = min t over all primitives whose own test accepts, ties to the
-// lowest primitive id (order independent).  Boxes are padded by the host builder, so the slab
+// The leaf's OWN box (bvh.rs:20-25): Leaf::may_intersect pushes a primitive onto the candidate list only if
+// aabb.rs:74-92 passes on the primitive's own exact box -- a slab test in plain f32, seeded with [-1e5, 1e5]
+// (constant.rs:3).  It DECIDES: a ray that triangle.rs:69-100 accepts within a few ulp of an edge lying on a face of a
+// flat box (every axis-aligned wall) is dropped by the reference, and so is any hit beyond 1e5.  The boxes of the inner
+// nodes never reject what the leaf's box accepts (rounding is monotone in the planes), so the reference's closest hit is
+//     min t over { p : own_box(p) passes  and  own_test(p) accepts },
+// whatever the tree.  The device keeps its fast search over ALL primitives (conservative boxes that only prune) and then
+// SETTLES the one primitive that decides the query -- the closest hit, or a connection's occluder:
+//   own_box_surely   one approximate slab test with a margin on every comparison: true = the literal test certainly
+//                    passes, so the winner of the unfiltered search is the winner of the filtered one (every other
+//                    candidate is no nearer);
+//   otherwise        (~1e-5 of the rays: the hit lies within ~1e-6 relative of a face of its own box, or a direction
+//                    component is ~0) the query is repeated LITERALLY: every primitive test followed by own_box_exact,
+//                    the reference's operations in the reference's order (retrace_flat / retrace_tree; cold code).
+// pbox: two rows per primitive id, {min.xyz, -} {max.xyz, -} as triangle.rs:102-118 / sphere.rs:31-38 compute them.
+// ------------------------------------------------------------------------------------------
+LR_DEV bool own_box_exact(float4 lo, float4 hi, V3 o, V3 d) {                   // aabb.rs:74-92, line by line
+  float mn = -kInf, mx = kInf;
+#define LR_AXIS(C)                                                                            \
+  {                                                                                           \
+    float inv_d = 1.0f / d.C;                                                                 \
+    float t1 = (lo.C - o.C) * inv_d;                                                          \
+    float t2 = (hi.C - o.C) * inv_d;                                                          \
+    float t_min = t1, t_max = t2;                                                             \
+    if (t1 > t2) { t_min = t2; t_max = t1; }                                                  \
+    if (mn < t_min) mn = t_min;                                                               \
+    if (mx > t_max) mx = t_max;                                                               \
+    if (mn > mx) return false;                                                                \
+  }
+  LR_AXIS(x) LR_AXIS(y) LR_AXIS(z)
+#undef LR_AXIS
+  return true;
+}
+// true = own_box_exact(lo, hi, o, d) is certainly true.  (ix, iy, iz) = 1/d to 1 ulp (v_rcp_f32; the traversal's clamped
+// reciprocals qualify because directions with a component below 1e-18 are left undecided: there the literal test meets
+// inf and NaN, whose comparisons this form does not model).  The literal test's slab parameters are
+// fl(fl(plane - o) * fl(1/d)); the ones below share the exact difference and differ by < 2.5e-7 relative, the margin is
+// 2^-20 relative + 1e-30 absolute on each side of every comparison the literal test makes between DIFFERENT axes (its
+// own axis always passes by construction: t_min <= t_max after the swap).  Every comparison is written so that a NaN
+// gives "undecided".
+LR_DEV bool own_box_surely(float4 lo, float4 hi, V3 o, V3 d, float ix, float iy, float iz) {
+  const float g = 9.5367431640625e-7f;                                          // 2^-20
+  const bool dir_ok = bool(__builtin_fabsf(d.x) >= 1e-18f) & bool(__builtin_fabsf(d.y) >= 1e-18f) & bool(__builtin_fabsf(d.z) >= 1e-18f);
+  float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
+  float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
+  float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
+  float nx = __builtin_fminf(ax, bx), fx = __builtin_fmaxf(ax, bx);
+  float ny = __builtin_fminf(ay, by), fy = __builtin_fmaxf(ay, by);
+  float nz = __builtin_fminf(az, bz), fz = __builtin_fmaxf(az, bz);
+  {
+#pragma clang fp contract(fast)
+    // entry parameters pushed up, exit parameters pulled down by the margin
+    nx = __builtin_fmaf(__builtin_fabsf(nx), g, nx); ny = __builtin_fmaf(__builtin_fabsf(ny), g, ny); nz = __builtin_fmaf(__builtin_fabsf(nz), g, nz);
+    fx = __builtin_fmaf(__builtin_fabsf(fx), -g, fx) - 1e-30f; fy = __builtin_fmaf(__builtin_fabsf(fy), -g, fy) - 1e-30f; fz = __builtin_fmaf(__builtin_fabsf(fz), -g, fz) - 1e-30f;
+  }
+  const float hi5 = kInf * (1.0f - 2.0f * g);
+  const bool ok = bool(nx <= __builtin_fminf(__builtin_fminf(fy, fz), hi5)) & bool(ny <= __builtin_fminf(__builtin_fminf(fx, fz), hi5)) &
+                  bool(nz <= __builtin_fminf(__builtin_fminf(fx, fy), hi5)) & bool(__builtin_fminf(__builtin_fminf(fx, fy), fz) >= -hi5);
+  return dir_ok & ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH traversal.  Closest hit = min t over the primitives whose own box passes (above) and whose own test accepts,
+// ties to the lowest primitive id (order independent).  The tree's boxes are padded by the host builder, so ITS slab
 // test may use fused / approximate arithmetic: it only prunes, never decides.
 //   SHADOW: accept only hits with t - dist <= EPS; stop at the first hit with t - dist < -EPS
-//   (then the closest hit is at least that near and scene.rs:129 rejects the connection).
+//   (then the closest hit is at least that near and scene.rs:129 rejects the connection); the occluder's id and
+//   distance are kept, because its own box has the last word (own_box_settle).
 // ------------------------------------------------------------------------------------------
 struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; };
 
@@ -254,7 +317,8 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
 }
 
 // One leaf (s.cur < 0): run the primitive tests of its range.  false = ray finished.
-template <bool SHADOW>
+// LITERAL (retrace_tree): a primitive whose own test accepts counts only if aabb.rs:74-92 passes on its own box (bvh.rs:20-25).
+template <bool SHADOW, bool LITERAL = false>
 LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n) {
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
@@ -275,14 +339,36 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t);
     if (!hit) continue;
+    if (LITERAL && !own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], s.o, s.d)) continue;
     if (SHADOW) {
       float diff = t - s.dist;
-      if (diff < -kEps) { s.occluded = true; return false; }
+      if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return false; }   // (the occluder: own_box_settle_tree looks at its box)
       if (diff > kEps) continue;
     }
     if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }   // closest-hit queries prune with s.t itself
   }
   return trav_pop<SHADOW>(sc, s, stk_n);
+}
+
+// The literal query on a tree scene (cold, see own_box_surely): the same walk -- the tree's padded boxes contain every
+// primitive's own box, so a primitive whose own box passes is reached -- with own_box_exact behind every primitive test.
+// A lane runs it alone (the lanes of its wave wait); its traversal stack is free, its walk being over.
+template <bool SHADOW>
+LR_DEV void retrace_tree(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
+  const uint32_t visits = s.visits, tests = s.tests;
+  trav_begin<SHADOW>(s, s.o, s.d, s.dist);
+  bool go = true;
+#pragma unroll 1
+  while (go) go = s.cur >= 0 ? trav_node<SHADOW>(sc, s, stk_n) : trav_leaf<SHADOW, true>(sc, s, stk_n);
+  s.visits += visits; s.tests += tests;
+}
+// settle the primitive that decided a finished walk (closest hit, in-window hit or occluder): certainly a candidate, or the literal query
+template <bool SHADOW>
+LR_DEV void own_box_settle_tree(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
+  const size_t pi = s.prim < 0 ? 0 : (size_t)s.prim;
+  const float4 lo = sc.pbox[2 * pi], hi = sc.pbox[2 * pi + 1];
+  const bool unsure = bool(s.prim >= 0) & !own_box_surely(lo, hi, s.o, s.d, s.ix, s.iy, s.iz);
+  if (unsure) retrace_tree<SHADOW>(sc, s, stk_n);
 }
 
 // A burst of traversal for the lanes with `go` set (while-while: the wave first descends inner nodes
@@ -336,6 +422,7 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
   trav_begin<SHADOW>(s, o, d, dist);
   bool go = true;
   while (__ballot(go) != 0) trav_burst<SHADOW>(sc, s, stk_n, go);
+  own_box_settle_tree<SHADOW>(sc, s, stk_n);
   TraceResult res; res.t = s.t; res.prim = s.prim; res.occluded = s.occluded; res.visits = s.visits; res.tests = s.tests;
   return res;
 }
@@ -353,6 +440,10 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
 typedef float RowVec __attribute__((ext_vector_type(4)));
 typedef RowVec __attribute__((address_space(4))) ConstRow;
 LR_DEV float4 row4(RowVec v) { return make_float4(v.x, v.y, v.z, v.w); }
+// A 16-B row requested WHERE THIS IS WRITTEN.  LLVM sinks an ordinary load below a branch when every use lies behind it -- which turns
+// "all rows of a stage in one round trip, then a rarely taken branch, then the uses" into one exposed round trip per group of
+// uses.  A volatile load stays put (one global_load_dwordx4, the usual vmcnt bookkeeping).
+LR_DEV float4 row_now(const float4* p) { return row4(*(const volatile RowVec*)p); }
 
 // One primitive of the flat loop: triangle.rs:69-100 / sphere.rs:42-55 and the closest-hit fold.  Returns
 // true when the loop may stop (SHADOW: every lane of the wave already knows it is occluded).
@@ -391,19 +482,54 @@ LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, T
       }
     }
   }
-  if (SHADOW) {
-    float diff = t - dist;
-    res.occluded = res.occluded | (hit & bool(diff < -kEps));
-    hit = hit & bool(!(diff > kEps));
-  }
+  // (SHADOW too: the closest hit of the connection; scene.rs:127-131's window is applied to it after its own box has been settled)
+  (void)dist;
   bool better = hit & bool(t < res.t);                   // rows come in primitive-id order: the first of equal hits is the lowest id
   res.t = better ? t : res.t;
   res.prim = better ? id : res.prim;
-#if LR_FLAT_SHADOW_EXIT
-  return SHADOW && __ballot(!res.occluded) == 0;
-#else
+  return false;
+}
+
+// The literal query on a flat scene (cold: see own_box_surely): bvh.rs:20-25,131-141 over every primitive in id order --
+// the primitive's own test, then aabb.rs:74-92 on its own box.  Runs under the lane mask of the undecided rays; the loop
+// index is wave-uniform, so the rows still arrive as scalar loads.
+LR_DEV void retrace_flat(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n, V3 o, V3 d, float& t_out, int& prim_out) {
+  const ConstRow* rows = (const ConstRow*)prims;
+  const ConstRow* boxes = (const ConstRow*)pbox;
+  float bt = 3.0e38f; int bp = -1;
+#pragma unroll 1
+  for (int k = 0; k < n; ++k) {
+    const float4 q0 = row4(rows[3 * k]), q1 = row4(rows[3 * k + 1]), q2 = row4(rows[3 * k + 2]);
+    const uint32_t idw = __float_as_uint(q0.w);
+    const int id = (int)(idw & 0x7fffffffu);
+    float t = 0.0f; bool hit;
+    if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
+    else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
+    if (hit && t < bt && own_box_exact(row4(boxes[2 * id]), row4(boxes[2 * id + 1]), o, d)) { bt = t; bp = id; }
+  }
+  t_out = bt; prim_out = bp;
+}
+// the winner `prim` of an unfiltered search is NOT certainly a candidate (lo, hi = its own box rows; prim < 0: nothing to settle)
+#ifndef LR_NO_SETTLE
+#define LR_NO_SETTLE 0                 // measurement only (tools/build_variant.sh): skip the own-box stage = the closest hit over ALL primitives of rounds 1-5
+#endif
+LR_DEV bool own_box_unsure(float4 lo, float4 hi, int prim, V3 o, V3 d) {
+#if LR_NO_SETTLE
   return false;
 #endif
+  return bool(prim >= 0) & !own_box_surely(lo, hi, o, d, __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+}
+// settle the winner of the unfiltered search (t, prim) of a flat scene: certainly a candidate, or the literal query
+LR_DEV void own_box_settle_flat(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n, V3 o, V3 d, float& t, int& prim) {
+  const int pi = prim < 0 ? 0 : prim;
+  const float4 lo = pbox[2 * pi], hi = pbox[2 * pi + 1];
+  if (own_box_unsure(lo, hi, prim, o, d)) retrace_flat(prims, pbox, n, o, d, t, prim);
+}
+// scene.rs:127-131 on the settled closest hit of a connection: nearer than the window = occluded, beyond it = no hit
+LR_DEV void shadow_window(float dist, float t, int& prim, bool& occluded) {
+  const float diff = t - dist;
+  occluded = bool(prim >= 0) & bool(diff < -kEps);
+  prim = diff > kEps ? -1 : prim;
 }
 
 // Small scenes (n_flat = number of primitives when <= kFlatMax, else 0): the SAH says a tree over a
@@ -411,8 +537,9 @@ LR_DEV bool flat_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist, T
 // primitive.  The loop index is wave-uniform, so the primitive rows arrive through the scalar cache
 // into SGPRs (s_load_dwordx4) and the loop is pure, fully converged VALU: no vector memory traffic,
 // no stack, no divergence.  Same tests, same tie rule => same result as traverse().
+// (traverse_flat_raw: the closest hit over all primitives, its own box not yet settled)
 template <bool SHADOW>
-LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, int n, V3 o, V3 d, float dist) {
+LR_DEV TraceResult traverse_flat_raw(const float4* __restrict__ prims, int n, V3 o, V3 d, float dist) {
   TraceResult res; res.t = 3.0e38f; res.prim = -1; res.occluded = false; res.visits = 0; res.tests = (uint32_t)n;
   // constant address space: uniform loads from it are always scalar (s_load), whatever the alias analysis thinks
   const ConstRow* rows = (const ConstRow*)prims;
@@ -428,6 +555,13 @@ LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, int n, V3 o, 
     if (k + 1 >= n) break;
     if (flat_test<SHADOW>(b0, b1, b2, o, d, dist, res)) break;
   }
+  return res;
+}
+template <bool SHADOW>
+LR_DEV TraceResult traverse_flat(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n, V3 o, V3 d, float dist) {
+  TraceResult res = traverse_flat_raw<SHADOW>(prims, n, o, d, dist);
+  own_box_settle_flat(prims, pbox, n, o, d, res.t, res.prim);
+  if (SHADOW) shadow_window(dist, res.t, res.prim, res.occluded);
   return res;
 }
 
@@ -1143,7 +1277,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
         if (__float_as_int(ro.w) >= 0) {
           float4 rd = st.ray_d[slot];
           active = true;
-          TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
+          TraceResult r = traverse_flat<false>(flat_prims, sc.pbox, sc.n_flat, v3(ro), v3(rd), 0.0f);
           st.hit[slot] = make_float2(r.t, __int_as_float(r.prim));
           if (!st.dense_shade) qid = r.prim < 0 ? kQMiss : (int)sc.prim_qid[r.prim];
           if (COUNT) n_tst += r.tests;
@@ -1199,6 +1333,7 @@ __global__ void __launch_bounds__(kBlock, LR_TRACE_WAVES) k_trace(DevScene sc, D
           bool f = has && fin;
           int key = -1;
           if (f) {
+            own_box_settle_tree<false>(sc, tr, stk_n);               // bvh.rs:20-25: the own box of the closest hit has the last word
             st.hit[slot] = make_float2(tr.t, __int_as_float(tr.prim));
             if (!st.dense_shade) key = tr.prim < 0 ? kQMiss : (int)sc.prim_qid[tr.prim];
             if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
@@ -1614,7 +1749,7 @@ __global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc,
         uint32_t slot = entry_slot(i);
         float4 ro = st.ray_o[slot], sd = st.sh_d[slot];             // shade advanced ray_o to the hit point = shadow origin (scene.rs:114-117)
         V3 o = v3(ro), dir = v3(sd);
-        TraceResult r = traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w);
+        TraceResult r = traverse_flat<true>(flat_prims, sc.pbox, sc.n_flat, o, dir, sd.w);
         n_q += (uint32_t)__builtin_popcountll(__ballot(true));
         if (COUNT) n_tst += r.tests;
         shadow_resolve(sc, st, slot, o, dir, r);
@@ -1652,6 +1787,7 @@ __global__ void __launch_bounds__(kBlock, LR_SHADOW_WAVES) k_shadow(DevScene sc,
       uint32_t slot = 0;
       while (true) {
         if (has && fin) {
+          own_box_settle_tree<true>(sc, tr, stk_n);
           TraceResult r; r.t = tr.t; r.prim = tr.prim; r.occluded = tr.occluded; r.visits = tr.visits; r.tests = tr.tests;
           if (COUNT) { n_vis += tr.visits; n_tst += tr.tests; }
           shadow_resolve(sc, st, slot, tr.o, tr.d, r);
@@ -1839,7 +1975,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
         float4 rd = st.ray_d[slot];
         active = true;
         TraceResult r;
-        if (FLAT) r = traverse_flat<false>(flat_prims, sc.n_flat, v3(ro), v3(rd), 0.0f);
+        if (FLAT) r = traverse_flat<false>(flat_prims, sc.pbox, sc.n_flat, v3(ro), v3(rd), 0.0f);
         else r = traverse<false>(sc, v3(ro), v3(rd), 0.0f, stk_n, nullptr);
         st.sh_w[slot] = make_float4(r.t, __int_as_float(r.prim), 0.0f, 0.0f);
         qid = r.prim < 0 ? kQMiss : (FLAT ? (int)s_qid[r.prim] : (int)sc.prim_qid[r.prim]);
@@ -1897,7 +2033,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
           float4 sd = st.sh_d[slot];
           V3 o = v3(ro), dir = v3(sd);
           TraceResult r;
-          if (FLAT) r = traverse_flat<true>(flat_prims, sc.n_flat, o, dir, sd.w);
+          if (FLAT) r = traverse_flat<true>(flat_prims, sc.pbox, sc.n_flat, o, dir, sd.w);
           else r = traverse<true>(sc, o, dir, sd.w, stk_n, nullptr);
           n_shq += 1;
           shadow_resolve(sc, st, slot, o, dir, r);
@@ -2037,13 +2173,15 @@ __global__ void __launch_bounds__(kBlock) k_selftest_intersect(DevScene sc, cons
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-  TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, nullptr);
+  TraceResult r = sc.n_flat > 0 ? traverse_flat<false>(flat_prims, sc.pbox, sc.n_flat, o, d, 0.0f) : traverse<false>(sc, o, d, 0.0f, stk_n, nullptr);
   prim_out[i] = r.prim; t_out[i] = r.prim >= 0 ? r.t : 0.0f;
 }
 
 // bvh.rs:131-141 with the candidate set widened to every primitive: the definition the tree must reproduce.  The loop
 // index is wave-uniform, so the rows arrive by scalar loads; tri_test / sphere_test are the render path's own.
-__global__ void __launch_bounds__(kBlock) k_selftest_brute(const float4* __restrict__ prims, int n_prims, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
+// pbox != null: the DEFINITION of the render path's closest hit (bvh.rs:20-25 + 131-141): a primitive counts only if aabb.rs:74-92
+// passes on its own exact box (own_box_exact, per primitive, no shortcut).
+__global__ void __launch_bounds__(kBlock) k_selftest_brute(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n_prims, const float* origins, const float* dirs, int* prim_out, float* t_out, int n) {
   int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
@@ -2058,6 +2196,7 @@ __global__ void __launch_bounds__(kBlock) k_selftest_brute(const float4* __restr
     float t = 0.0f; bool hit;
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
+    if (hit && pbox) hit = own_box_exact(row4(((const ConstRow*)pbox)[2 * (size_t)id]), row4(((const ConstRow*)pbox)[2 * (size_t)id + 1]), o, d);
     if (hit && (t < best || (t == best && id < bp))) { best = t; bp = id; }
   }
   if (valid) { prim_out[i] = bp; t_out[i] = bp >= 0 ? best : 0.0f; }

@@ -162,10 +162,8 @@ LR_DEV void flat_test_pair(float4 q0, float4 q1, float4 q2, V3 o, V3 d, V3 sd, f
   bool betterA = hitA & bool(tA < r.t);                  // rows come in primitive-id order: the first of equal hits is the lowest id
   r.t = betterA ? tA : r.t;
   r.prim = betterA ? id : r.prim;
-  float diff = tB - sdist;                               // scene.rs:127-131 window, as flat_test<true>
-  r.occluded = r.occluded | (hitB & bool(diff < -kEps));
-  hitB = hitB & bool(!(diff > kEps));
-  bool betterB = hitB & bool(tB < r.st);
+  (void)sdist;                                           // the connection's CLOSEST hit, as flat_test<true>: scene.rs:127-131's window
+  bool betterB = hitB & bool(tB < r.st);                 // is applied after its own box has been settled (traverse_flat_pair)
   r.st = betterB ? tB : r.st;
   r.sprim = betterB ? id : r.sprim;
 }
@@ -182,7 +180,7 @@ LR_DEV PairHit traverse_flat_pair(const float4* __restrict__ prims, int n, V3 o,
     if (k + 1 >= n) break;
     flat_test_pair(b0, b1, b2, o, d, sd, sdist, has_sh, r);
   }
-  return r;
+  return r;                                               // (both winners still to be settled: k_path_flat)
 }
 
 // ---- stages shared by the flat and the tree kernel -------------------------------------------------------------------
@@ -206,12 +204,14 @@ struct PathCtl {
   bool has_sh;                         // sh_d / sh_w hold a direct-light connection that is still to be tested
   bool finished;                       // the sample in rad ended (its radiance is complete)
   bool fresh;                          // no work item yet
+  bool pend;                           // k_path_tree: the connection's walk is over, its outcome is parked in LDS until the next vertex
 };
 
 #ifndef LR_PATH_WAVES
 #define LR_PATH_WAVES 6
 #endif
-constexpr int kRecStride = 5;          // float4 rows per staged shading record: 80 B, so 16 records start in 16 different bank groups
+constexpr int kRecStride = 7;          // float4 rows per staged record: the 4 shading rows + the 2 rows of the primitive's own box (+ 1: 112 B, an odd number of
+                                       // 16-B bank groups, so consecutive records start in different ones)
 
 // ---- spare camera samples: the finish stage as a dense batch ---------------------------------------------------------
 // Paths of a wave end a few at a time (8 of 64 lanes per retire point on the 100k-triangle scene), and fold + next work item +
@@ -435,6 +435,10 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
     float4 v = sc.shade[i];
     s_rec[(i >> 2) * kRecStride + (i & 3u)] = (RowVec){v.x, v.y, v.z, v.w};
   }
+  for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 2u; i += kBlock) {      // rows 4, 5: the primitive's own box (bvh.rs:20-25)
+    float4 v = sc.pbox[i];
+    s_rec[(i >> 1) * kRecStride + 4u + (i & 1u)] = (RowVec){v.x, v.y, v.z, v.w};
+  }
   for (uint32_t i = tid; i < (uint32_t)sc.n_emitters * 3u && i < (uint32_t)kFlatMax * 3u; i += kBlock) {
     float4 v = sc.emit[i];
     s_emit[i] = (RowVec){v.x, v.y, v.z, v.w};
@@ -446,7 +450,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.emit = (const LdsRow*)s_emit;
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
-  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false;
   uint32_t sq = 0;                                                   // the lane's queue of spares (sq_count / sq_head)
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   LR_TL(st, 0)
@@ -479,6 +483,23 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       if (sm != 0) {
         const V3 sd = c.has_sh ? v3(ls.sh_d.v) : d;
         PairHit h = traverse_flat_pair(flat_prims, sc.n_flat, o, d, sd, ls.sh_d.v.w, c.has_sh);
+        // bvh.rs:20-25: the own box of each winner has the last word (lr_kernels.h own_box_surely); box rows from LDS
+        {
+          const int pa = h.prim < 0 ? 0 : h.prim, pb = h.sprim < 0 ? 0 : h.sprim;
+          const bool ua = own_box_unsure(rec(pa, 4), rec(pa, 5), h.prim, o, d);
+          const bool ub = own_box_unsure(rec(pb, 4), rec(pb, 5), h.sprim, o, sd);
+          if (ua | ub) {                                             // cold: ~1e-5 of the rays
+#pragma unroll 1
+            for (int w = 0; w < 2; ++w) {
+              if (w ? ub : ua) {
+                float t_; int p_;
+                retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, w ? sd : d, t_, p_);
+                if (w) { h.st = t_; h.sprim = p_; } else { h.t = t_; h.prim = p_; }
+              }
+            }
+          }
+          shadow_window(ls.sh_d.v.w, h.st, h.sprim, h.occluded);
+        }
         t = h.t; prim = h.prim;
         if (c.has_sh) {
           V3 L = path_shadow_resolve(v3(ls.rad.v), o, sd, v3(ls.sh_w.v), h.occluded, h.sprim, h.st, rec);
@@ -486,7 +507,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
           c.has_sh = false;
         }
       } else {
-        TraceResult r = traverse_flat<false>(flat_prims, sc.n_flat, o, d, 0.0f);
+        TraceResult r = traverse_flat_raw<false>(flat_prims, sc.n_flat, o, d, 0.0f);
+        const int pa = r.prim < 0 ? 0 : r.prim;
+        if (own_box_unsure(rec(pa, 4), rec(pa, 5), r.prim, o, d)) retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, d, r.t, r.prim);
         t = r.t; prim = r.prim;
       }
     }
@@ -623,8 +646,9 @@ LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
 }
 // one primitive of a leaf against the lane's ray; true = a connection found its occluder (the walk is over)
-template <bool CONN, class LS>
-LR_DEV bool ptrav_prim(PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
+// LITERAL (ptrav_settle's re-trace): a primitive whose own test accepts counts only if aabb.rs:74-92 passes on its own box (bvh.rs:20-25)
+template <bool CONN, bool LITERAL, class LS>
+LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
   uint32_t idw = __float_as_uint(q0.w);
   int id = (int)(idw & 0x7fffffffu);
   float t; bool hit;
@@ -636,9 +660,10 @@ LR_DEV bool ptrav_prim(PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0,
   else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
 #endif
   if (!hit) return false;
+  if (LITERAL && !own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], o, d)) return false;
   if (CONN && conn) {
     float diff = t - ls.sh_d.v.w;
-    if (diff < -kEps) { s.occluded = true; return true; }
+    if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return true; }   // (the occluder: ptrav_settle looks at its own box)
     if (diff > kEps) return false;
   }
   if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }
@@ -650,7 +675,7 @@ LR_DEV bool ptrav_prim(PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0,
 #ifndef LR_LEAF_UNROLL2
 #define LR_LEAF_UNROLL2 1
 #endif
-template <bool CONN, class LS>
+template <bool CONN, bool LITERAL = false, class LS>
 LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, const uint32_t* stk_n) {
   const V3 o = v3(ls.ray_o.v), d = ptrav_dir<CONN>(conn, ls);
   uint32_t enc = (uint32_t)~s.cur;
@@ -661,11 +686,11 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
   for (uint32_t k = 0; ; k += 2) {
     const bool more1 = k + 1 < count;
     if (more1) { b0 = q[3 * k + 3]; b1 = q[3 * k + 4]; b2 = q[3 * k + 5]; }
-    if (ptrav_prim<CONN>(s, ls, conn, o, d, a0, a1, a2)) return false;
+    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, a0, a1, a2)) return false;
     if (!more1) break;
     const bool more2 = k + 2 < count;
     if (more2) { a0 = q[3 * k + 6]; a1 = q[3 * k + 7]; a2 = q[3 * k + 8]; }
-    if (ptrav_prim<CONN>(s, ls, conn, o, d, b0, b1, b2)) return false;
+    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, b0, b1, b2)) return false;
     if (!more2) break;
   }
 #else
@@ -673,7 +698,7 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
   for (uint32_t k = 0; k < count; ++k) {
     float4 q0 = n0, q1 = n1, q2 = n2;
     if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
-    if (ptrav_prim<CONN>(s, ls, conn, o, d, q0, q1, q2)) return false;
+    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, q0, q1, q2)) return false;
   }
 #endif
   return ptrav_pop(sc, s, stk_n);
@@ -717,9 +742,24 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, u
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
-#ifndef LR_INWALK_RESOLVE
-#define LR_INWALK_RESOLVE 1            // resolve a finished connection inside the walk once this many lanes have one (0: only at retire points)
+// The literal walk of (ray_o, conn ? sh_d : ray_d) for a lane whose winner is not certainly a candidate under bvh.rs:20-25
+// (lr_kernels.h own_box_surely): the same tree -- its padded boxes contain every primitive's own box -- with own_box_exact behind
+// every primitive test.  Cold (~1e-5 of the rays); the lane's traversal stack is free, its walk being over.
+// LR_SETTLE_PRELOAD: the vertex's shading rows travel with the box rows of the settle stage (one round trip, 16 more live registers)
+#ifndef LR_SETTLE_PRELOAD
+#define LR_SETTLE_PRELOAD 0
 #endif
+template <bool CONN, class LS>
+LR_DEV void ptrav_retrace(const DevScene& sc, const LS& ls, bool conn, uint32_t* stk_n, float& t, int& prim, bool& occluded) {
+  PTrav s; ptrav_begin(s, ptrav_dir<CONN>(conn, ls));
+  bool go = true;
+#pragma unroll 1
+  while (go) go = s.cur >= 0 ? ptrav_node<CONN>(sc, s, ls, conn, stk_n) : ptrav_leaf<CONN, true>(sc, s, ls, conn, stk_n);
+  t = s.t; prim = s.prim; occluded = s.occluded;
+}
+// the outcome of a connection's walk in one word: 0 = nothing in the window, w + 1 = primitive w hit inside it, -(x + 1) = occluded by x
+LR_DEV uint32_t conn_word(const PTrav& s) { return s.prim < 0 ? 0u : (s.occluded ? (uint32_t)-(s.prim + 1) : (uint32_t)(s.prim + 1)); }
+
 #ifndef LR_RETIRE_EIGHTHS
 #define LR_RETIRE_EIGHTHS 4            // the walk stops for a retire point when this many eighths of the wave's rays are still under way
 #endif
@@ -742,6 +782,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   __shared__ RowVec s_emit[NEE ? kEmitLds * 3 : 1];
+  __shared__ uint32_t s_conn[NEE ? kBlock : 1];                      // conn_word of the lane's parked connection (PathCtl::pend)
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
@@ -760,7 +801,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   ls.emit = emit_lds ? (const LdsRow*)s_emit : nullptr;
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
-  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true;
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false;
   PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f));
   bool go = false;                                                   // the lane's walk is under way
   uint32_t sq = 0;                                                   // the lane's queue of one spare
@@ -769,26 +810,94 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   while (true) {
     // ================= retire point (converged) =================
     // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, the spare count, has_sh, occluded.)
-    // (a) connections whose walk is over: scene.rs:127-147, then the lane starts its continuation ray
+    // (a) connections whose walk is over: the outcome is PARKED (one word in LDS) and the lane starts its continuation ray.  It is
+    // settled and resolved (scene.rs:127-147) at the lane's next vertex, where the wave's finished rays are densest: resolving the
+    // one or two connections that end per burst on the spot ran ~70 instructions at 1-3 lanes, and the own-box test (bvh.rs:20-25)
+    // would have doubled that.  The radiance still receives the connection before anything the next vertex adds: same sums.
     if constexpr (NEE) {
       const bool fs = __float_as_int(ls.ray_o.v.w) >= 0 && !go && c.has_sh;
-      if (__ballot(fs) != 0) {
-        LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(fs));)
-        if (fs) {
-          V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), v3(ls.sh_d.v), v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
-          ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
-          c.has_sh = false;
-          ptrav_begin(tr, v3(ls.ray_d.v));
-          go = true;
-        }
-        LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq;)
+      if (fs) {
+        s_conn[threadIdx.x] = conn_word(tr);
+        c.has_sh = false; c.pend = true;
+        ptrav_begin(tr, v3(ls.ray_d.v));
+        go = true;
       }
     }
-    // (b) continuation rays whose walk is over: the vertex
+    // (b) continuation rays whose walk is over: the own boxes of what they and the parked connection hit (bvh.rs:20-25), the
+    // connection's radiance, then the vertex
     const bool fm = __float_as_int(ls.ray_o.v.w) >= 0 && !go;         // (a) left only closest-hit walks among these
     if (__ballot(fm) != 0) {
-      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
+      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime();)
+      // ONE round trip for every row this stage reads: the hit's shading record and own box and -- pt-direct -- the own box, normal and
+      // emission of what the parked connection reached.  (Each dependent trip through the vector-memory path costs thousands of
+      // cycles under the walk's load.)
+      const V3 o = v3(ls.ray_o.v);
+      bool hitv = fm && tr.prim >= 0;
+      size_t pr = hitv ? (size_t)tr.prim : 0;
+      float4 blo = row_now(sc.pbox + 2 * pr), bhi = row_now(sc.pbox + 2 * pr + 1);
+#if LR_SETTLE_PRELOAD
+      float4 r0 = row_now(sc.shade + 4 * pr), r1 = row_now(sc.shade + 4 * pr + 1), r2 = row_now(sc.shade + 4 * pr + 2), r3 = row_now(sc.shade + 4 * pr + 3);
+#endif
+      bool pm = false, cocc = false; int cp = -1; float ct = 0.0f;
+      float4 clo = blo, chi = bhi, csh = blo, cem = bhi;
+      if constexpr (NEE) {
+        pm = fm && c.pend;
+        LR_DIAG_ONLY(dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(pm));)
+        if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; }
+        const size_t pc = cp >= 0 ? (size_t)cp : 0;
+        clo = row_now(sc.pbox + 2 * pc); chi = row_now(sc.pbox + 2 * pc + 1); csh = row_now(sc.shade + 4 * pc); cem = row_now(sc.shade + 4 * pc + 2);
+      }
+      // settle (lr_kernels.h own_box_surely): is each winner certainly a candidate?
+#if LR_NO_SETTLE
+      bool ur = false, uc = false;
+#else
+      bool ur = hitv & !own_box_surely(blo, bhi, o, v3(ls.ray_d.v), tr.ix, tr.iy, tr.iz);
+      bool uc = false;
+      if constexpr (NEE) uc = own_box_unsure(clo, chi, cp, o, v3(ls.sh_d.v));
+#endif
+      if (ur | uc) {                                                 // cold: the literal walk, then the rows of what it found
+        bool dummy = false;
+        if constexpr (NEE) {
+#pragma unroll 1
+          for (int it = 0; it < 2; ++it) {                           // (one copy of the walk)
+            const bool conn = it == 0;
+            if (conn ? uc : ur) {
+              float t_ = 0.0f; int p_ = -1; bool o_ = false;
+              ptrav_retrace<true>(sc, ls, conn, stk_n, t_, p_, o_);
+              if (conn) { ct = t_; cp = p_; cocc = o_; } else { tr.t = t_; tr.prim = p_; }
+            }
+          }
+          const size_t pc = cp >= 0 ? (size_t)cp : 0;
+          csh = sc.shade[4 * pc]; cem = sc.shade[4 * pc + 2];
+        } else {
+          if (ur) ptrav_retrace<false>(sc, ls, false, stk_n, tr.t, tr.prim, dummy);
+        }
+        hitv = fm && tr.prim >= 0; pr = hitv ? (size_t)tr.prim : 0;
+#if LR_SETTLE_PRELOAD
+        r0 = sc.shade[4 * pr]; r1 = sc.shade[4 * pr + 1]; r2 = sc.shade[4 * pr + 2]; r3 = sc.shade[4 * pr + 3];
+#endif
+      }
+      if constexpr (NEE) {
+        if (__ballot(pm) != 0) {
+          if (pm) {
+            const V3 dir = v3(ls.sh_d.v);
+            // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives
+            // it again, the same bits (centre from the shading record, r^2 from the box rows)
+            if (cp >= 0 && !cocc && (__float_as_uint(csh.w) >> 31)) { const V3 co = o - v3(csh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, dir, &ct); }
+            auto crec = [&](int, int row) -> float4 { return row == 0 ? csh : cem; };
+            V3 L = path_shadow_resolve(v3(ls.rad.v), o, dir, v3(ls.sh_w.v), cocc, cp, ct, crec);
+            ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+            c.pend = false;
+          }
+        }
+      }
+      LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
+#if LR_SETTLE_PRELOAD
+      auto prec = [&](int, int row) -> float4 { return row == 0 ? r0 : (row == 1 ? r1 : (row == 2 ? r2 : r3)); };
+      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, prec, s_stat);
+#else
       path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, s_stat);
+#endif
       LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
@@ -828,22 +937,17 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
 #else
       ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, stk_n, go);
 #endif
-#if LR_INWALK_RESOLVE
       if constexpr (NEE) {
-        // connections whose walk is over do not wait for the retire point once LR_INWALK_RESOLVE of them have gathered: they are
-        // resolved here and their lanes walk on with the continuation ray, so a retire point is about vertices
+        // a connection whose walk is over does not wait for the retire point: its outcome is parked and the lane walks on with the
+        // continuation ray (see (a))
         const bool dc = live && !go && c.has_sh;
-        if (__builtin_popcountll(__ballot(dc)) >= LR_INWALK_RESOLVE) {
-          if (dc) {
-            V3 L = path_shadow_resolve(v3(ls.rad.v), v3(ls.ray_o.v), v3(ls.sh_d.v), v3(ls.sh_w.v), tr.occluded, tr.prim, tr.t, rec);
-            ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
-            c.has_sh = false;
-            ptrav_begin(tr, v3(ls.ray_d.v));
-            go = true;
-          }
+        if (dc) {
+          s_conn[threadIdx.x] = conn_word(tr);
+          c.has_sh = false; c.pend = true;
+          ptrav_begin(tr, v3(ls.ray_d.v));
+          go = true;
         }
       }
-#endif
     } while (__builtin_popcountll(__ballot(go)) > thresh);
 #if LR_PRIO_ANY
     LR_SETPRIO(LR_PRIO_RETIRE);

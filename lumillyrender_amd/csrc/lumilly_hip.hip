@@ -96,7 +96,7 @@ struct LrScene {
   hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] setup done, [1], [2] group 1 / 2 batch done
   int n_cus = 0;
   // scene blob
-  DevBuf<float4> nodes, prims, flat, shade, emit, texels;
+  DevBuf<float4> nodes, prims, flat, shade, pbox, emit, texels;
   DevBuf<uint32_t> texels_rgbe;        // the IBL map as RGBE words when every texel re-encodes exactly (lr_device.h)
   DevBuf<uint8_t> prim_qid;
   DevScene dev;
@@ -106,6 +106,7 @@ struct LrScene {
   double bvh_build_ms = 0.0;           // device LBVH build time (0 when the host supplied the tree)
   int film_w = 0, film_h = 0;
   int n_prims = 0;
+  std::vector<int32_t> user_id;        // device primitive id -> the caller's index (pack_scene: device ids follow the tree's leaf order)
   // render state (kept between calls)
   DevBuf<float4> ray_o, ray_d, thr, rad, acc, sh_d, sh_w, partial;
   DevBuf<float2> hit;
@@ -252,6 +253,29 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   if (d.camera.type < 0 || d.camera.type > LR_CAMERA_OMNIDIRECTIONAL) fail(LR_EINVAL, "unknown camera type");
   const int np = d.n_prims;
 
+  // DEVICE PRIMITIVE IDS = the tree's leaf order.  bvh.rs:131-141 keeps the FIRST minimum of the candidate list and bvh.rs:38-45 fills
+  // that list left subtree first, so an exact distance tie goes to the primitive a depth-first walk of the reference's tree meets
+  // first -- which is the order of the description's bvh_prim_order (lr_host_build_bvh reproduces the reference's SAH recursion and
+  // its sorts, host/bvh_build.cpp).  Numbering the primitives by it makes the kernels' tie rule ("lowest id", explicit in the tree
+  // walk, implicit in the flat loop's row order) the reference's.  Everything indexed by primitive id below (shading records, own
+  // boxes, BSDF ids, the rows' id words) uses device ids; the emitter table keeps INSTANCE order (objects.rs:19-24); diagnostics
+  // translate back (LrScene::user_id).  Without a caller's tree (device LBVH build) the ids are the caller's: ties by instance order.
+  std::vector<LrPrimitive> prim_dev((size_t)np);
+  std::vector<int32_t> rank((size_t)np), leaf_order((size_t)np);
+  s.user_id.assign((size_t)np, 0);
+  {
+    std::vector<char> seen((size_t)np, 0);
+    for (int k = 0; k < np; ++k) {
+      int id = device_bvh ? k : d.bvh_prim_order[k];
+      if (id < 0 || id >= np || seen[(size_t)id]) fail(LR_EINVAL, "BVH primitive order is not a permutation");
+      seen[(size_t)id] = 1;
+      rank[(size_t)id] = k; s.user_id[(size_t)k] = id; leaf_order[(size_t)k] = k;
+      prim_dev[(size_t)k] = d.prims[id];
+    }
+  }
+  const LrPrimitive* const dprims = prim_dev.data();                    // primitives by DEVICE id
+  const int32_t* const dorder = leaf_order.data();                      // leaf position -> device id (the identity)
+
   // materials (weight: lambert.rs:27-30 and the other four `weight` impls)
   std::vector<float4> mats((size_t)d.n_materials * 3);
   for (int i = 0; i < d.n_materials; ++i) {
@@ -267,13 +291,14 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
 
   // per-primitive shading rows + emitter table (objects.rs:19-24) in instance order
   std::vector<float4> shade((size_t)np * 4), emit;
+  std::vector<float4> pbox((size_t)std::max(np, 1) * 2, make_float4(0, 0, 0, 0));   // the primitive's own exact box (lr_device.h): bvh.rs:20-25 decides with it
   std::vector<uint8_t> qid((size_t)np);
   std::vector<float> area((size_t)np);
   std::vector<uint8_t> sliver((size_t)np, 0);
   std::vector<float> tri_a((size_t)np, 0.0f);                        // |e1||e2| per triangle (0 for spheres): the scale of Moeller-Trumbore's absolute error
   for (int q = 0; q < kNumShadeQueues - 1; ++q) s.mat_present[q] = false;
   for (int i = 0; i < np; ++i) {
-    const LrPrimitive& p = d.prims[i];
+    const LrPrimitive& p = dprims[i];
     if (p.material < 0 || p.material >= d.n_materials) fail(LR_EINVAL, "primitive material index out of range");
     uint32_t mw = (uint32_t)p.material;
     if (p.type == LR_PRIM_TRIANGLE) {                            // triangle.rs:25-40
@@ -287,6 +312,10 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       shade[4 * i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
       area[i] = nrm * 0.5f;
+      pbox[2 * (size_t)i] = make_float4(std::fmin(std::fmin(p.v[0], p.v[3]), p.v[6]), std::fmin(std::fmin(p.v[1], p.v[4]), p.v[7]),      // triangle.rs:102-118
+                                        std::fmin(std::fmin(p.v[2], p.v[5]), p.v[8]), 0.0f);
+      pbox[2 * (size_t)i + 1] = make_float4(std::fmax(std::fmax(p.v[0], p.v[3]), p.v[6]), std::fmax(std::fmax(p.v[1], p.v[4]), p.v[7]),
+                                            std::fmax(std::fmax(p.v[2], p.v[5]), p.v[8]), 0.0f);
       // triangle.rs:69-100 divides by det = e1 . (d x e2) = |e1||e2| sin(phi) cos(theta): with a small angle phi between the edges
       // at p0 the distance t = (e2 . qv) / det carries a relative error of ~eps / (sin(phi) cos(theta)) for EVERY direction, enough
       // to report the hit in front of the triangle's own (padded) box.  Such triangles are exempt from distance culling.
@@ -299,6 +328,8 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
       shade[4 * i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
       area[i] = 4.0f * kPi * (p.v[3] * p.v[3]);
+      pbox[2 * (size_t)i] = make_float4(p.v[0] - p.v[3], p.v[1] - p.v[3], p.v[2] - p.v[3], p.v[3] * p.v[3]);   // sphere.rs:31-38; .w = r^2 (k_path_tree re-derives a parked hit's distance)
+      pbox[2 * (size_t)i + 1] = make_float4(p.v[0] + p.v[3], p.v[1] + p.v[3], p.v[2] + p.v[3], 0.0f);
     } else fail(LR_EINVAL, "unknown primitive type");
     for (int k = 0; k < 3; ++k) shade[4 * i + 1 + k] = mats[3 * (size_t)p.material + k];
     int mt = d.materials[p.material].type;
@@ -307,19 +338,20 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
   float emission_area = 0.0f;
   std::vector<int> emitters;
-  for (int i = 0; i < np; ++i) {
+  for (int i = 0; i < np; ++i) {                                 // (i = the caller's index: instance order)
     const LrMaterial& m = d.materials[d.prims[i].material];
     if (m.type != LR_MAT_LAMBERT) continue;
     float e2 = m.emission[0] * m.emission[0] + m.emission[1] * m.emission[1] + m.emission[2] * m.emission[2];
     if (e2 > 0.0f) emitters.push_back(i);
   }
-  for (int i : emitters) emission_area += area[i];               // objects.rs:24 (.sum() in instance order)
+  for (int i : emitters) emission_area += area[rank[i]];         // objects.rs:24 (.sum() in instance order)
   {
     float cum = 0.0f;
     for (int i : emitters) {
       const LrPrimitive& p = d.prims[i];
-      cum += area[i];                                            // objects.rs:41
-      float pdf = (1.0f / area[i]) * area[i] / emission_area;    // objects.rs:46 with triangle.rs:147 / sphere.rs:82
+      const float a_i = area[rank[i]];
+      cum += a_i;                                                // objects.rs:41
+      float pdf = (1.0f / a_i) * a_i / emission_area;            // objects.rs:46 with triangle.rs:147 / sphere.rs:82
       if (p.type == LR_PRIM_TRIANGLE) {
         emit.push_back(make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)LR_PRIM_TRIANGLE)));
         emit.push_back(make_float4(p.v[3], p.v[4], p.v[5], pdf));
@@ -384,10 +416,10 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
         uint32_t enc = (uint32_t)~ch, first = enc >> 3, count = enc & 7u;
         if ((uint64_t)first + count > (uint64_t)np) fail(LR_EINVAL, "BVH leaf range out of bounds");
         for (uint32_t k = first; k < first + count; ++k) {
-          int id = d.bvh_prim_order[k];
-          if (id < 0 || id >= np || seen[id]) fail(LR_EINVAL, "BVH primitive order is not a permutation");
+          int id = dorder[k];
+          if (seen[id]) fail(LR_EINVAL, "BVH leaf ranges overlap");
           seen[id] = 1;
-          const LrPrimitive& p = d.prims[id];
+          const LrPrimitive& p = dprims[id];
           if (p.type == LR_PRIM_TRIANGLE) {                        // e1, e2 of triangle.rs:71-72
             prims[3 * k] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
             prims[3 * k + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
@@ -466,7 +498,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       HIP_OK(hipStreamSynchronize(s.stream));
       for (int k = 0; k < np; ++k) { uint32_t id = __builtin_bit_cast(uint32_t, rows[3 * (size_t)k].w) & 0x7fffffffu; if (id < (uint32_t)np) leaf_area[k] = tri_a[id]; }
     } else if (!device_bvh) {
-      for (int k = 0; k < np; ++k) leaf_area[k] = tri_a[d.bvh_prim_order[k]];
+      for (int k = 0; k < np; ++k) leaf_area[k] = tri_a[dorder[k]];
     } else if (np == 1) leaf_area[0] = tri_a[0];
     std::vector<float4> wide;
     wide.reserve(nodes.size());
@@ -488,11 +520,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     if (!built_on_device) s.prims.upload(prims, s.stream);
   }
   if (np > 0 && np <= kFlatMax) {
-    // small scenes are tested without a tree (traverse_flat): the same rows IN PRIMITIVE-ID ORDER, so that "first
-    // strictly nearer hit wins" is the lowest-id tie rule; padded by three primitives (the loop requests whole groups)
+    // small scenes are tested without a tree (traverse_flat): the same rows IN DEVICE-ID ORDER -- the reference's candidate order
+    // (above) -- so that "first strictly nearer hit wins" is bvh.rs:131-141's first minimum; padded by three primitives (the loop
+    // requests whole groups)
     std::vector<float4> flat((size_t)np * 3 + 9, make_float4(0, 0, 0, 0));
     for (int id = 0; id < np; ++id) {
-      const LrPrimitive& p = d.prims[id];
+      const LrPrimitive& p = dprims[id];
       if (p.type == LR_PRIM_TRIANGLE) {
         flat[3 * id] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, (uint32_t)id));
         flat[3 * id + 1] = make_float4(p.v[3] - p.v[0], p.v[4] - p.v[1], p.v[5] - p.v[2], 0.0f);
@@ -504,7 +537,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     }
     s.flat.upload(flat, s.stream);
   }
-  s.shade.upload(shade, s.stream);
+  s.shade.upload(shade, s.stream); s.pbox.upload(pbox, s.stream);
   s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
   if (!texels_rgbe.empty()) s.texels_rgbe.upload(texels_rgbe, s.stream);
   s.prim_qid.upload(qid, s.stream);
@@ -512,7 +545,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
 
   DevScene& v = s.dev;
   std::memset(&v, 0, sizeof(v));
-  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.emit = s.emit.p;
+  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.pbox = s.pbox.p; v.emit = s.emit.p;
   v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
   v.texels_rgbe = texels_rgbe.empty() ? nullptr : s.texels_rgbe.p;
   v.n_flat = (np > 0 && np <= kFlatMax) ? np : 0;
@@ -1341,11 +1374,12 @@ int lr_selftest_intersect(LrScene* s, int n, const float* origins, const float* 
     if (n > 0) hipLaunchKernelGGL(k_selftest_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s->stream, dsc, (const float4*)s->flat.p, s->stack_depth, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) if (prim_out[i] >= 0 && (size_t)prim_out[i] < s->user_id.size()) prim_out[i] = s->user_id[(size_t)prim_out[i]];   // device id -> the caller's index
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   })
 }
 
-int lr_selftest_brute(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
+static int selftest_brute(LrScene* s, bool own_box, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) {
   LR_TRY({
     if (!s || !origins || !dirs || !prim_out || !t_out || n < 0) fail(LR_EINVAL, "bad argument");
     HIP_OK(hipSetDevice(s->device));
@@ -1353,12 +1387,15 @@ int lr_selftest_brute(LrScene* s, int n, const float* origins, const float* dirs
     dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
-    if (n > 0) hipLaunchKernelGGL(k_selftest_brute, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, (const float4*)s->prims.p, s->n_prims, dor.p, ddr.p, dpr.p, dt.p, n);
+    if (n > 0) hipLaunchKernelGGL(k_selftest_brute, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, (const float4*)s->prims.p, own_box ? (const float4*)s->pbox.p : (const float4*)nullptr, s->n_prims, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) if (prim_out[i] >= 0 && (size_t)prim_out[i] < s->user_id.size()) prim_out[i] = s->user_id[(size_t)prim_out[i]];   // device id -> the caller's index
     HIP_OK(hipMemcpy(t_out, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   })
 }
+int lr_selftest_brute(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) { return selftest_brute(s, false, n, origins, dirs, prim_out, t_out); }
+int lr_selftest_brute_own_box(LrScene* s, int n, const float* origins, const float* dirs, int32_t* prim_out, float* t_out) { return selftest_brute(s, true, n, origins, dirs, prim_out, t_out); }
 int lr_selftest_sky(LrScene* s, int n, const float* dirs, float* rgb_out) {
   LR_TRY({
     if (!s || !dirs || !rgb_out || n < 0) fail(LR_EINVAL, "bad argument");

@@ -45,6 +45,8 @@ def lib():
     l.lr_selftest_rng.argtypes = [C.c_int, C.c_uint32, up, up, up, fp, C.c_int]
     l.lr_selftest_intersect.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
     l.lr_selftest_brute.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    if hasattr(l, "lr_selftest_brute_own_box"):            # round 6; older builds (tools/ab4.py baselines) lack it
+        l.lr_selftest_brute_own_box.argtypes = [vp, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
     l.lr_selftest_emitter_pick.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int32)]
     l.lr_selftest_sky.argtypes = [vp, C.c_int, fp, fp]
     if hasattr(l, "lr_selftest_material"):                 # diagnostics entry points of round 4; older builds (tools/ab4.py baselines) lack them
@@ -178,13 +180,15 @@ class Scene:
         return o, d
 
     def intersect(self, origins, dirs, brute=False):
-        """Closest hit per ray: through the traversal path lr_render uses (flat loop or tree), or with brute=True
-        against every primitive (the definition, bvh.rs:131-141).  Returns (primitive index or -1, distance)."""
+        """Closest hit per ray: through the traversal path lr_render uses (flat loop or tree); with brute=True against every
+        primitive behind its own exact box (the definition, bvh.rs:20-25 + 131-141, evaluated per primitive); with
+        brute="all" against every primitive without any box (the definition of rounds 1-5).
+        Returns (primitive index or -1, distance)."""
         o, d = self._rays(origins, dirs)
         n = o.shape[0]
         prim = np.empty(n, dtype=np.int32)
         t = np.empty(n, dtype=np.float32)
-        fn = lib().lr_selftest_brute if brute else lib().lr_selftest_intersect
+        fn = lib().lr_selftest_brute if brute == "all" else (lib().lr_selftest_brute_own_box if brute else lib().lr_selftest_intersect)
         _check(fn(self._h, n, _fptr(o), _fptr(d), prim.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(t)))
         return prim, t
 

@@ -2,15 +2,27 @@
 //
 // Replaces BVH::construct (bvh.rs:69-127): same full-sweep SAH over the three axes with the
 // reference's cost model T = 2*T_aabb + (A(S1)*N(S1) + A(S2)*N(S2)) * T_tri / A(S), T_aabb = 1,
-// T_tri = 2 (bvh.rs:71-72,111).  Differences, none of which can change an image:
+// T_tri = 2 (bvh.rs:71-72,111), decided on the primitives' EXACT boxes (triangle.rs:102-118, sphere.rs:31-38)
+// with the reference's sequence of sorts -- x, y, z, then the chosen axis, each one STABLE (the reference's
+// sort_unstable_by_key leaves the order of equal centres open; a stable sort is one valid outcome, and the
+// one the parity tests' CPU restatement takes).
+//
+// THE LEAF ORDER IS THE REFERENCE'S CANDIDATE ORDER.  bvh.rs:131-141 keeps the FIRST minimum of the candidate
+// list, and Node::may_intersect (bvh.rs:38-45) fills that list left subtree first: on an exact distance tie
+// the primitive that comes first in a depth-first walk of the reference's tree wins.  `order` (the
+// description's bvh_prim_order) lists the primitives in exactly that order -- lr_scene_create numbers them by
+// it, so "lowest device id" IS "first candidate"  -- including inside a leaf of several
+// primitives, whose range is ordered by the reference's own recursion (ref_order).
+//
+// Differences from the reference's tree, none of which can change an image:
 //   * leaves may hold up to `max_leaf` primitives when the SAH says splitting does not pay
 //     (the reference always splits down to one, bvh.rs:76-78);
 //   * nodes are emitted in the flat two-boxes-per-node layout of LrBvhNode;
-//   * every stored box is padded so that the device slab test is strictly conservative: the
-//     closest-hit result is defined by the primitive tests alone, the tree only
-//     decides how many of them run;
-//   * sorting is deterministic (ties by primitive index; the reference uses sort_unstable);
-//   * below depth 32 the split falls back to the object median to bound the traversal stack.
+//   * every STORED box is padded (and a sphere's grown) so that the device slab test is strictly conservative:
+//     the tree only decides how many primitive tests run; whether a primitive is a candidate is decided by
+//     the literal slab test on its own exact box, on the device (bvh.rs:20-25, csrc/lr_kernels.h);
+//   * below depth 32 the split falls back to the object median to bound the traversal stack; the leaf order
+//     of such a subtree is the median split's, not the reference's (exact ties only, pathological inputs only).
 #include "host_internal.h"
 #include <algorithm>
 #include <chrono>
@@ -44,7 +56,8 @@ Box prim_box(const LrPrimitive& p) {
 }
 
 struct Builder {
-  const std::vector<Box>& boxes;
+  const std::vector<Box>& boxes;        // exact boxes: every SAH decision and the order
+  const std::vector<Box>& store;        // what is stored: spheres grown (build_bvh)
   std::vector<float> centre[3];
   std::vector<int> idx;
   std::vector<float> pre, suf;
@@ -54,18 +67,53 @@ struct Builder {
   static constexpr float T_AABB = 1.0f, T_TRI = 2.0f;
   static constexpr int MEDIAN_DEPTH = 32;
 
-  Builder(const std::vector<Box>& b, BvhResult& o, int ml) : boxes(b), out(o), max_leaf(ml) {}
+  Builder(const std::vector<Box>& b, const std::vector<Box>& st, BvhResult& o, int ml) : boxes(b), store(st), out(o), max_leaf(ml) {}
 
-  void sort_axis(int lo, int hi, int axis) {
+  void sort_axis(int lo, int hi, int axis) {                   // bvh.rs:83-86,117-119 (stable: see the header)
     const std::vector<float>& c = centre[axis];
-    std::sort(idx.begin() + lo, idx.begin() + hi, [&c](int a, int b) { return c[a] < c[b] || (c[a] == c[b] && a < b); });
+    std::stable_sort(idx.begin() + lo, idx.begin() + hi, [&c](int a, int b) { return c[a] < c[b]; });
   }
   Box range_box(int lo, int hi) const { Box b; b.reset(); for (int i = lo; i < hi; ++i) b.grow(boxes[idx[i]]); return b; }
+  Box range_store(int lo, int hi) const { Box b; b.reset(); for (int i = lo; i < hi; ++i) b.grow(store[idx[i]]); return b; }
 
-  int32_t make_leaf(int lo, int hi, const Box& box) {
+  // bvh.rs:80-115: the best (axis, split) of idx[lo, hi) under the SAH, first minimum over the splits of an axis and over the
+  // axes; leaves the range sorted by z.  n >= 2.
+  void find_split(int lo, int hi, const Box& box, int* axis_out, int* k_out, float* cost_out) {
+    const int n = hi - lo;
+    int best_axis = -1, best_k = -1; float best_cost = 0.0f;
+    const float s_a = box.area();
+    for (int axis = 0; axis < 3; ++axis) {
+      sort_axis(lo, hi, axis);
+      Box b; b.reset();
+      for (int i = 0; i < n; ++i) { b.grow(boxes[idx[lo + i]]); pre[i] = b.area(); }
+      b.reset();
+      for (int i = n - 1; i >= 1; --i) { b.grow(boxes[idx[lo + i]]); suf[i] = b.area(); }
+      for (int i = 0; i < n - 1; ++i) {                   // left = [0..i], right = [i+1..n)
+        float c = 2.0f * T_AABB + (pre[i] * (float)(i + 1) + suf[i + 1] * (float)(n - i - 1)) * T_TRI / s_a;
+        if (!(c == c)) c = INFINITY;                      // zero-area parents (degenerate input)
+        if (best_axis < 0 || c < best_cost) { best_cost = c; best_axis = axis; best_k = i + 1; }
+      }
+    }
+    *axis_out = best_axis; *k_out = best_k; *cost_out = best_cost;
+  }
+  // idx[lo, hi) in the order a depth-first walk of the REFERENCE's subtree over it visits the leaves (bvh.rs:69-127 down to
+  // single primitives, no node emitted): the candidate order of bvh.rs:38-45 inside a leaf of several primitives
+  void ref_order(int lo, int hi) {
+    if (hi - lo < 2) return;
+    int axis, k; float cost;
+    find_split(lo, hi, range_box(lo, hi), &axis, &k, &cost);
+    sort_axis(lo, hi, axis);
+    ref_order(lo, lo + k); ref_order(lo + k, hi);
+  }
+
+  int32_t make_leaf(int lo, int hi, const Box& box, int split_axis = 0, int split_k = 0, bool median_below = false) {
     int first = (int)out.order.size();
-    // inside a leaf keep ascending primitive order: ties in distance resolve to the lowest index
-    std::sort(idx.begin() + lo, idx.begin() + hi);
+    if (!median_below && hi - lo > 1) {
+      // inside a leaf: the reference's candidate order (see the header).  The caller's find_split of this range IS the reference's
+      // sweep (a second one would start from another order of the equal centres): apply its split, recurse as the reference does
+      sort_axis(lo, hi, split_axis);
+      ref_order(lo, lo + split_k); ref_order(lo + split_k, hi);
+    }
     for (int i = lo; i < hi; ++i) out.order.push_back(idx[i]);
     out.sah_cost += (double)(box.area() / root_area) * (hi - lo) * T_TRI;
     return ~(int32_t)((first << 3) | (hi - lo));
@@ -87,22 +135,10 @@ struct Builder {
     if (n == 1) { out.max_depth = std::max(out.max_depth, depth); return make_leaf(lo, hi, box); }
     int best_axis = -1, best_k = -1; float best_cost = 0.0f;
     if (depth < MEDIAN_DEPTH) {
-      float s_a = box.area();
-      for (int axis = 0; axis < 3; ++axis) {
-        sort_axis(lo, hi, axis);
-        Box b; b.reset();
-        for (int i = 0; i < n; ++i) { b.grow(boxes[idx[lo + i]]); pre[i] = b.area(); }
-        b.reset();
-        for (int i = n - 1; i >= 1; --i) { b.grow(boxes[idx[lo + i]]); suf[i] = b.area(); }
-        for (int i = 0; i < n - 1; ++i) {                   // left = [0..i], right = [i+1..n)
-          float c = 2.0f * T_AABB + (pre[i] * (float)(i + 1) + suf[i + 1] * (float)(n - i - 1)) * T_TRI / s_a;
-          if (!(c == c)) c = INFINITY;                      // zero-area parents (degenerate input)
-          if (best_axis < 0 || c < best_cost) { best_cost = c; best_axis = axis; best_k = i + 1; }
-        }
-      }
-      if (n <= max_leaf && (float)n * T_TRI <= best_cost) { out.max_depth = std::max(out.max_depth, depth); return make_leaf(lo, hi, box); }
+      find_split(lo, hi, box, &best_axis, &best_k, &best_cost);
+      if (n <= max_leaf && (float)n * T_TRI <= best_cost) { out.max_depth = std::max(out.max_depth, depth); return make_leaf(lo, hi, box, best_axis, best_k); }
     } else {
-      if (n <= max_leaf) { out.max_depth = std::max(out.max_depth, depth); return make_leaf(lo, hi, box); }
+      if (n <= max_leaf) { out.max_depth = std::max(out.max_depth, depth); return make_leaf(lo, hi, box, 0, 0, true); }
       float ext[3] = {box.mx[0] - box.mn[0], box.mx[1] - box.mn[1], box.mx[2] - box.mn[2]};
       best_axis = ext[0] >= ext[1] && ext[0] >= ext[2] ? 0 : (ext[1] >= ext[2] ? 1 : 2);
       best_k = n / 2;
@@ -110,6 +146,7 @@ struct Builder {
     sort_axis(lo, hi, best_axis);
     int mid = lo + best_k;
     Box lb = range_box(lo, mid), rb = range_box(mid, hi);
+    const Box lbs = range_store(lo, mid), rbs = range_store(mid, hi);
     int32_t me = (int32_t)out.nodes.size();
     out.nodes.push_back(LrBvhNode());
     std::memset(&out.nodes[me], 0, sizeof(LrBvhNode));
@@ -117,7 +154,7 @@ struct Builder {
     int32_t l = build(lo, mid, lb, depth + 1);
     int32_t r = build(mid, hi, rb, depth + 1);
     LrBvhNode& node = out.nodes[me];
-    store_child(node, 0, lb); store_child(node, 1, rb);
+    store_child(node, 0, lbs); store_child(node, 1, rbs);
     node.child[0] = l; node.child[1] = r;
     return me;
   }
@@ -156,12 +193,14 @@ BvhResult build_bvh(const LrPrimitive* prims, int n, int max_leaf, const float* 
   // |co|^2 <= extent^2, so the test can accept rays that pass up to sqrt(r^2 + ~2e-7 extent^2) from
   // the centre (a radius-1 sphere seen from 1e5 away "grows" by tens of units).  The box must cover
   // every ray the primitive test can accept, so sphere boxes grow by that amount (2x margin).
+  std::vector<Box> store(boxes);                      // what the nodes store; `boxes` stays exact: the SAH and the order are the reference's
+  Box all_exact = all;
   for (int i = 0; i < n; ++i) {
     if (prims[i].type != LR_PRIM_SPHERE) continue;
     float r = std::fabs(prims[i].v[3]);
     float grow = std::sqrt(r * r + 4e-7f * diag * diag) - r;
-    for (int a = 0; a < 3; ++a) { boxes[i].mn[a] -= grow; boxes[i].mx[a] += grow; }
-    all.grow(boxes[i]);
+    for (int a = 0; a < 3; ++a) { store[i].mn[a] -= grow; store[i].mx[a] += grow; }
+    all.grow(store[i]);
   }
 
   LrBvhNode root; std::memset(&root, 0, sizeof(root));
@@ -171,17 +210,18 @@ BvhResult build_bvh(const LrPrimitive* prims, int n, int max_leaf, const float* 
     out.nodes.push_back(root);
     out.max_depth = 1;
   } else {
-    Builder b(boxes, out, max_leaf);
+    Builder b(boxes, store, out, max_leaf);
     for (int a = 0; a < 3; ++a) {
       b.centre[a].resize((size_t)n);
-      for (int i = 0; i < n; ++i) b.centre[a][i] = (boxes[i].mn[a] + boxes[i].mx[a]) / 2.0f;   // aabb.rs:61 centre
+      for (int i = 0; i < n; ++i)                       // triangle.rs:116 centre = (max + min) / 2; sphere.rs:36 centre = position
+        b.centre[a][i] = prims[i].type == LR_PRIM_SPHERE ? prims[i].v[a] : (boxes[i].mx[a] + boxes[i].mn[a]) / 2.0f;
     }
     b.idx.resize((size_t)n); for (int i = 0; i < n; ++i) b.idx[i] = i;
     b.pre.resize((size_t)n); b.suf.resize((size_t)n + 1);
-    b.root_area = std::fmax(all.area(), 1e-30f);
+    b.root_area = std::fmax(all_exact.area(), 1e-30f);
     out.nodes.reserve((size_t)n);
     out.order.reserve((size_t)n);
-    int32_t r = b.build(0, n, all, 0);
+    int32_t r = b.build(0, n, all_exact, 0);
     if (r < 0) {
       // a single leaf: wrap it so that node 0 is always an inner node
       LrBvhNode w; std::memset(&w, 0, sizeof(w));

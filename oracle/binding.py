@@ -20,7 +20,8 @@ from lumillyrender_amd import abi  # noqa: E402  (POD struct mirrors only)
 class LrOracleStats(C.Structure):
     """lr_oracle.cpp: struct LrOracleStats"""
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("sky_fetches", C.c_uint64), ("seconds", C.c_double)]
+                ("prim_tests", C.c_uint64), ("sky_fetches", C.c_uint64), ("seconds", C.c_double),
+                ("tie_flips", C.c_uint64), ("order_dependent", C.c_uint64)]
 
 
 # LR_ORACLE_LIB=<path>: the sanitizer build of the checker (`make -C oracle asan`), used for both roles
@@ -76,6 +77,7 @@ def lib(fast=False):
     l.lr_oracle_prim_sample.argtypes = [C.POINTER(abi.LrPrimitive), C.c_float, C.c_float, fp]
     l.lr_oracle_prim_sample.restype = None
     l.lr_oracle_intersect_batch.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, C.c_float, C.c_int, fp, fp, C.POINTER(C.c_int32), fp]
+    l.lr_oracle_bvh_leaf_order.argtypes = [C.POINTER(abi.LrSceneDesc), C.POINTER(C.c_int32)]
     l.lr_oracle_sky_batch.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, fp]
     l.lr_oracle_sky_batch.restype = None
     l.lr_oracle_emitter_pick.argtypes = [C.POINTER(abi.LrSceneDesc), C.c_int, fp, C.POINTER(C.c_int32)]
@@ -98,12 +100,16 @@ def f3(v):
     return (C.c_float * len(v))(*[float(x) for x in v])
 
 
-BRUTE, BVH, BVH_ORDERED = 0, 1, 2
+BRUTE, BVH, BVH_ORDERED, OWNBOX, OWNBOX_TREE, OWNBOX_ORDERED, BVH_AUDIT, OWNBOX_INDEX, OWNBOX_TREE_INDEX = 0, 1, 2, 3, 4, 5, 6, 7, 8
+# OWNBOX (every primitive behind its own exact box, bvh.rs:20-25 + aabb.rs:74-92; exact ties to the first primitive of the reference's
+# candidate order) is what the HIP path implements; BVH with pad == 0 is the reference line by line and gives the same result on
+# every ray (OWNBOX_TREE is its alias: fast on the 100k-triangle scenes); the _INDEX forms break exact ties by primitive index, which
+# is what a device-built tree gives.
 
 
-def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE, pad=0.0, with_stats=False, fast=False):
-    """Render with the CPU oracle.  mode BRUTE = the closest-hit definition; BVH with pad == 0 is the
-    reference's literal tree + candidate traversal (bvh.rs / aabb.rs)."""
+def render(description, params, tiles=None, n_tiles=None, threads=0, mode=OWNBOX, pad=0.0, with_stats=False, fast=False):
+    """Render with the CPU oracle.  mode OWNBOX = the closest-hit definition (every primitive behind its own exact box);
+    BVH with pad == 0 is the reference's literal tree + candidate traversal (bvh.rs / aabb.rs); OWNBOX_ORDERED needs pad > 0."""
     d = description.desc
     w, h = int(d.camera.resolution[0]), int(d.camera.resolution[1])
     if tiles is None:
@@ -119,7 +125,7 @@ def render(description, params, tiles=None, n_tiles=None, threads=0, mode=BRUTE,
     return (img, st) if with_stats else img
 
 
-def intersect(description, origins, dirs, mode=BRUTE, pad=0.0):
+def intersect(description, origins, dirs, mode=OWNBOX, pad=0.0):
     o = np.ascontiguousarray(origins, dtype=np.float32)
     d = np.ascontiguousarray(dirs, dtype=np.float32)
     n = o.shape[0]
@@ -130,6 +136,16 @@ def intersect(description, origins, dirs, mode=BRUTE, pad=0.0):
     if rc != 0:
         raise RuntimeError(f"lr_oracle_intersect_batch failed: {rc}")
     return prim, t
+
+
+def bvh_leaf_order(description):
+    """Primitive indices in the candidate order of the reference's tree (depth-first, left first; bvh.rs:38-45)."""
+    n = int(description.desc.n_prims)
+    out = np.empty(n, dtype=np.int32)
+    k = lib().lr_oracle_bvh_leaf_order(description.desc_ptr, out.ctypes.data_as(C.POINTER(C.c_int32)))
+    if k != n:
+        raise RuntimeError(f"lr_oracle_bvh_leaf_order: {k}")
+    return out
 
 
 def sky_batch(description, dirs):

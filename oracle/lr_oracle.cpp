@@ -22,11 +22,26 @@
 //     + - * / sqrt and integer ops) so that the HIP kernels can reproduce them bit for bit.
 //     They are accurate to ~1-2 ulp (tests compare them with numpy).
 //
-// Closest-hit semantics (bvh.rs:130-141): minimum distance over every primitive whose own test
-// accepts the ray; on exactly equal distances the lowest primitive index wins (the reference's
-// winner depends on its non-deterministic tree shape).  mode 0 = brute force (the definition),
-// mode 1 = the reference's SAH tree + collect-all-candidates traversal (bvh.rs, aabb.rs) with an
-// optional conservative box padding.
+// Closest-hit semantics (bvh.rs:20-25,130-141): a primitive is a candidate only if ITS OWN exact box passes
+// aabb.rs:74-92 (Leaf::may_intersect; the slab test is seeded with [-1e5, 1e5], constant.rs:3); the result is the
+// minimum distance over the candidates whose own test accepts the ray.  The boxes of inner nodes never reject what
+// the leaf's box accepts (f32 rounding is monotone in the box planes; tests/test_oracle_properties.py checks it on
+// edge-aimed rays), so this is tree-independent up to EXACT distance ties, where the reference keeps the first
+// minimum in the candidate order of its tree (bvh.rs:38-45,131-141).
+//   mode 3 (OWNBOX)      = that definition: every primitive, own exact box, own test; an exact tie goes to the primitive that comes
+//                          first in the reference's candidate order (the depth-first leaf order of its SAH tree with stable sorts; the
+//                          tree is built for that order only).  What the HIP path implements with a host-built tree since round 6.
+//   mode 1 (BVH)         = the reference line by line: SAH tree + collect-all-candidates walk, first minimum in candidate order
+//                          (pad = 0).  Equal to mode 3 on every ray (mode 6 audits it); mode 4 (OWNBOX_TREE) is its alias at pad 0
+//   mode 7 (OWNBOX_INDEX) / 8 (OWNBOX_TREE_INDEX) = the definition / the tree walk at pad 0 with exact ties to the lowest primitive INDEX:
+//                          what the HIP path gives on a device-built tree (no reference order to follow)
+//   mode 0 (BRUTE)       = minimum over ALL primitives, no box at all, ties to the lowest index (rounds 1-5 defined the device by it;
+//                          kept as the checker of lr_selftest_brute and of the box-free traversal tests)
+//   mode 2 (BVH_ORDERED) = near-first walk with early out over padded boxes (= mode 0)
+//   mode 5 (OWNBOX_ORDERED) = mode 2 with the primitive's own exact box behind its test and mode 3's tie rule (= mode 3; needs
+//                          pad > 0 for the inner boxes; the "optimized" CPU baseline)
+//   mode 6 (BVH_AUDIT)   = mode 1 at pad 0, and every query is also answered by the definition (mode 3): LrOracleStats counts the
+//                          queries that differ by an exact tie (tie_flips) and in any other way (order_dependent); both must stay 0
 //
 // Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off, no fast-math).
 
@@ -672,6 +687,7 @@ struct BVH {
       for (int i = 0; i < n - 1; ++i) {
         float s1_n = (float)(i + 1), s2_n = (float)(n - i - 1);
         float c = 2.0f * t_aabb + (s1_a[i] * s1_n + s2_a[n - i - 2] * s2_n) * t_tri / s_a;
+        if (!(c == c)) c = INFINITY;                                             // OrderedFloat puts NaN last (zero-area parents)
         if (i == 0 || c < cmin) { cmin = c; arg = i; }                           // min_by_key: first minimum
       }
       if (!have || cmin < best_cost) { have = true; best_cost = cmin; best_axis = axis; best_index = arg + 1; }
@@ -768,7 +784,7 @@ CamSample camera_sample(const LrCamera& c, int x, int y, const Draw4& d) {
 // ------------------------------------------------------------------------------------------
 // Scene  (scene.rs, objects.rs, sky.rs)
 // ------------------------------------------------------------------------------------------
-struct Counters { uint64_t segments = 0, shadow_rays = 0, node_visits = 0, prim_tests = 0, sky_fetches = 0, samples = 0; };
+struct Counters { uint64_t segments = 0, shadow_rays = 0, node_visits = 0, prim_tests = 0, sky_fetches = 0, samples = 0, tie_flips = 0, order_dependent = 0; };
 
 struct Scene {
   std::vector<Prim> prims;
@@ -776,6 +792,7 @@ struct Scene {
   std::vector<int> emission;            // objects.rs:19-23: emitter list in instance order
   float emission_area = 0.0f;           // objects.rs:24
   BVH bvh;
+  std::vector<int> rank;                // primitive -> its position in the reference tree's candidate order (bvh.rs:38-45: depth first, left first)
   LrSky sky;
   std::vector<float> texels;
   LrCamera camera;
@@ -799,6 +816,11 @@ struct Scene {
     return v3(texels[index * 3], texels[index * 3 + 1], texels[index * 3 + 2]);
   }
 
+  // Leaf::may_intersect (bvh.rs:20-25) without the tree: aabb.rs:74-92 on the primitive's own exact box
+  bool own_box_passes(int i, const Ray& ray) const {
+    AABB own; own.mn = prims[(size_t)i].bmin; own.mx = prims[(size_t)i].bmax; own.centre = prims[(size_t)i].bcentre;
+    return aabb_is_intersect(own, ray, 0.0f);
+  }
   // Objects::intersect -> BVH::intersect (objects.rs:63, bvh.rs:131-141)
   bool intersect(const Ray& ray, Intersection* out, Counters* ct, bool shadow = false) const {
     bool found = false; Intersection best; best.distance = 0.0f; best.prim = -1;
@@ -809,7 +831,17 @@ struct Scene {
         if (ct) ct->prim_tests++;
         if (prim_intersect(prims[i], ray, &it) && (!found || it.distance < best.distance)) { best = it; best.prim = (int)i; found = true; }
       }
-    } else if (mode == 2) {
+    } else if (mode == 3 || mode == 7) {
+      // bvh.rs:20-25 without the tree: the leaf's own box decides whether the primitive is a candidate; exact ties go to the
+      // primitive that comes first in the reference's candidate order (mode 3) or to the lowest index (mode 7)
+      for (size_t i = 0; i < prims.size(); ++i) {
+        if (ct) ct->node_visits++;
+        if (!own_box_passes((int)i, ray)) continue;
+        Intersection it;
+        if (ct) ct->prim_tests++;
+        if (prim_intersect(prims[i], ray, &it) && (!found || it.distance < best.distance || (mode == 3 && it.distance == best.distance && rank[i] < rank[(size_t)best.prim]))) { best = it; best.prim = (int)i; found = true; }
+      }
+    } else if (mode == 2 || mode == 5) {
       // "optimized" CPU baseline: the same tree, walked near child first with an explicit
       // stack, subtrees entered beyond the best hit so far are skipped, no candidate vector.  Boxes only prune
       // (pad > 0 keeps them conservative), ties go to the lowest primitive index: same result as mode 0.
@@ -827,8 +859,8 @@ struct Scene {
         if (b.leaf_index >= 0) {
           Intersection it; int i = b.leaf_index;
           if (ct) ct->prim_tests++;
-          if (prim_intersect(prims[i], ray, &it)) {
-            bool better = !found || it.distance < best.distance || (it.distance == best.distance && i < best.prim);
+          if (prim_intersect(prims[i], ray, &it) && (mode != 5 || own_box_passes(i, ray))) {
+            bool better = !found || it.distance < best.distance || (it.distance == best.distance && (mode == 5 ? rank[(size_t)i] < rank[(size_t)best.prim] : i < best.prim));
             if (better) { best = it; best.prim = i; found = true; }
           }
           continue;
@@ -850,21 +882,45 @@ struct Scene {
         bvh.may_intersect(bvh.root, ray, pad, cand, nullptr);
         for (size_t k = 0; k < cand.size(); ++k) {
           Intersection it; int i = cand[k];
-          if (prim_intersect(prims[i], ray, &it) && (!found || it.distance < best.distance || (it.distance == best.distance && i < best.prim))) { best = it; best.prim = i; found = true; }
+          if (prim_intersect(prims[i], ray, &it) && (mode != 5 || own_box_passes(i, ray)) &&
+              (!found || it.distance < best.distance || (it.distance == best.distance && (mode == 5 ? rank[(size_t)i] < rank[(size_t)best.prim] : i < best.prim)))) { best = it; best.prim = i; found = true; }
         }
       }
     } else {
       std::vector<int> cand;
-      if (bvh.root >= 0) bvh.may_intersect(bvh.root, ray, pad, cand, ct ? &ct->node_visits : nullptr);
+      if (bvh.root >= 0) bvh.may_intersect(bvh.root, ray, (mode == 4 || mode == 6 || mode == 8) ? 0.0f : pad, cand, ct ? &ct->node_visits : nullptr);
       for (size_t k = 0; k < cand.size(); ++k) {
         Intersection it; int i = cand[k];
         if (ct) ct->prim_tests++;
         if (prim_intersect(prims[i], ray, &it)) {
           // min_by keeps the first minimum in candidate order; with pad > 0 (conservative mode)
           // ties resolve to the lowest primitive index so that the result equals mode 0
-          bool better = !found || it.distance < best.distance || (pad > 0.0f && it.distance == best.distance && i < best.prim);
+          // (mode 8: ties to the lowest index, the rule of mode 7)
+          bool better = !found || it.distance < best.distance || ((pad > 0.0f || mode == 8) && it.distance == best.distance && i < best.prim);
           if (better) { best = it; best.prim = i; found = true; }
         }
+      }
+      if (mode == 6 && ct) {
+        // AUDIT of the literal walk (mode 1 at pad 0 is what was just evaluated): the definition (mode 3: every primitive behind its
+        // own box, lowest index on ties) on the same ray.  tie_flips = same distance bits, another primitive (an exact tie the
+        // reference's candidate order decides); order_dependent = anything else -- a query whose result would depend on the tree.
+        // (scenes of more than 64 primitives: the definition's tie rule on the walk's own candidate list -- that the list holds
+        //  every primitive whose own box passes is checked on ray batches, tests/test_oracle_properties.py)
+        bool f3 = false; Intersection b3; b3.distance = 0.0f; b3.prim = -1;
+        if (prims.size() <= 64) {
+          for (size_t i = 0; i < prims.size(); ++i) {
+            if (!own_box_passes((int)i, ray)) continue;
+            Intersection it;
+            if (prim_intersect(prims[i], ray, &it) && (!f3 || it.distance < b3.distance || (it.distance == b3.distance && rank[i] < rank[(size_t)b3.prim]))) { b3 = it; b3.prim = (int)i; f3 = true; }
+          }
+        } else {
+          for (size_t k = 0; k < cand.size(); ++k) {
+            Intersection it; int i = cand[k];
+            if (prim_intersect(prims[(size_t)i], ray, &it) && (!f3 || it.distance < b3.distance || (it.distance == b3.distance && rank[(size_t)i] < rank[(size_t)b3.prim]))) { b3 = it; b3.prim = i; f3 = true; }
+          }
+        }
+        if (f3 != found || (found && b3.distance != best.distance)) ct->order_dependent++;
+        else if (found && b3.prim != best.prim) ct->tie_flips++;
       }
     }
     if (found) *out = best;
@@ -986,7 +1042,16 @@ bool build_scene(const LrSceneDesc* desc, const LrRenderParams* params, int mode
   s->depth = params ? params->depth : 5; s->depth_limit = params ? params->depth_limit : 64;
   s->no_direct_emitter = params ? params->no_direct_emitter != 0 : false;
   s->mode = mode; s->pad = pad;
-  if (mode != 0) s->bvh.build(s->prims);
+  if (mode != 0 && mode != 7) s->bvh.build(s->prims);
+  s->rank.assign(s->prims.size(), 0);
+  if (mode != 0 && mode != 7 && s->bvh.root >= 0) {
+    std::vector<int> stack(1, s->bvh.root); int k = 0;
+    while (!stack.empty()) {
+      const BNode& b = s->bvh.nodes[(size_t)stack.back()]; stack.pop_back();
+      if (b.leaf_index >= 0) { s->rank[(size_t)b.leaf_index] = k++; continue; }
+      stack.push_back(b.right); stack.push_back(b.left);
+    }
+  }
   return true;
 }
 
@@ -1018,11 +1083,13 @@ extern "C" {
 struct LrOracleStats {
   uint64_t samples, segments, shadow_rays, node_visits, prim_tests, sky_fetches;
   double seconds;
+  uint64_t tie_flips, order_dependent;     // mode 6 (audit of the literal walk against the definition, see Scene::intersect)
 };
 
-// mode 0: brute force; mode 1: reference SAH tree + collect-all traversal, boxes padded by `pad`
+// mode 0: brute force over all primitives; mode 1: reference SAH tree + collect-all traversal, boxes padded by `pad`
 // (pad = 0 is the literal reference); mode 2: the same tree walked near-first with early-out (the "optimized"
-// CPU baseline; needs pad > 0 to stay exact).  n_threads <= 0 -> hardware_concurrency.
+// CPU baseline; needs pad > 0 to stay exact); mode 3: every primitive behind its own exact box (the definition the
+// HIP path implements); mode 4: mode 3 through the reference's tree (pad is ignored); mode 5: mode 3 through the near-first walk of mode 2 (pad > 0).  n_threads <= 0 -> hardware_concurrency.
 int lr_oracle_render(const LrSceneDesc* desc, const LrRenderParams* params, const LrTile* tiles, int n_tiles,
                      float* rgb_out, size_t row_stride_floats, int n_threads, int mode, float pad, LrOracleStats* stats) {
   if (!desc || !params || (!tiles && n_tiles > 0) || !rgb_out || params->spp <= 0) return LR_EINVAL;
@@ -1067,10 +1134,25 @@ int lr_oracle_render(const LrSceneDesc* desc, const LrRenderParams* params, cons
     for (auto& c : counters) {
       stats->samples += c.samples; stats->segments += c.segments; stats->shadow_rays += c.shadow_rays;
       stats->node_visits += c.node_visits; stats->prim_tests += c.prim_tests; stats->sky_fetches += c.sky_fetches;
+      stats->tie_flips += c.tie_flips; stats->order_dependent += c.order_dependent;
     }
     stats->seconds = std::chrono::duration<double>(t1 - t0).count();
   }
   return LR_OK;
+}
+
+// The candidate order of the reference's tree (bvh.rs:38-45: left subtree first): order_out[k] = primitive index of the k-th leaf
+// of a depth-first walk.  bvh.rs:131-141 keeps the first minimum in this order; the host builder's bvh_prim_order must equal it.
+int lr_oracle_bvh_leaf_order(const LrSceneDesc* desc, int32_t* order_out) {
+  Scene s; if (!build_scene(desc, nullptr, 1, 0.0f, &s)) return LR_EINVAL;
+  std::vector<int> stack; int k = 0;
+  if (s.bvh.root >= 0) stack.push_back(s.bvh.root);
+  while (!stack.empty()) {
+    const BNode& b = s.bvh.nodes[(size_t)stack.back()]; stack.pop_back();
+    if (b.leaf_index >= 0) { order_out[k++] = b.leaf_index; continue; }
+    stack.push_back(b.right); stack.push_back(b.left);
+  }
+  return k;
 }
 
 // ---- unit hooks for known-answer tests ------------------------------------------------------

@@ -26,7 +26,7 @@ def films():
         if gen and not gc.have_generated_assets():
             print("skipped (generated assets missing):", gc.film_name(case)); continue
         d = gc.load_scene(name, edit, w, h)
-        img = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.BRUTE)
+        img = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.OWNBOX)
         path = os.path.join(gc.GOLDEN, gc.film_name(case))
         np.save(path, img)
         print(path, img.shape, float(np.nanmean(img)))
@@ -53,12 +53,12 @@ def functions():
     # a10 / a11 / a8: closest hit over the flat Cornell scene (12 triangles + 2 spheres) and over the 100k-triangle tree
     desc = gc.load_scene("cbox-spheres.toml", None, 16, 16)
     o, d = gc.rays_in_box(512, (0, 0, -100), (556, 548, 560), 21)
-    prim, t = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    prim, t = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     out["cbox_prim"], out["cbox_t"] = prim, t
     if gc.have_generated_assets():
         desc = gc.load_scene("mesh-box.toml", None, 16, 16)
         o, d = gc.rays_at(**gc.MESH_RAYS)
-        prim, t = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+        prim, t = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
         out["mesh_prim"], out["mesh_t"] = prim, t
     # a13-a16 (+ f1): sample / brdf / coef of the five BSDFs
     inp = gc.material_inputs()

@@ -69,6 +69,64 @@ STATED_SPP_CASES = [
 ]
 
 
+# BASELINE.json configs[0..4] AT THEIR STATED FILM SIZE and spp (round 6): main.rs:80-122 runs per pixel of the W x H film, and
+# pixel footprints, the thin lens' sensor_pixel_area (camera.rs:391) and which geometric edges a pixel straddles all depend on
+# the resolution -- an 8 x 6 film of the same scene sees none of it (the own-box semantics of bvh.rs:20-25 showed at 1024 x 1024
+# only).  RNG keys are (pixel index, sample), so the oracle can render SCATTERED TILES of the full-size film: 64 tiles of 16 x 16
+# pixels, one per cell of an 8 x 8 grid at a position that differs from cell to cell (16 384 pixels, 196 KB as .npy), plus -- for
+# configs[1] -- the whole pixel rows through the images of the box's edges (rows 114, 231, 419, 1001: where round 5's closest
+# hit over ALL primitives left the reference).  name -> (scene, edit, W, H, spp, integrator, seed, needs assets, extra whole rows)
+STATED_SIZE_CASES = {
+    "c1": ("cbox-spheres.toml", None, 256, 256, 16, 0, 0, False, ()),
+    "c2": ("cbox-spheres.toml", None, 1024, 1024, 1024, 1, 0, False, (114, 231, 419, 1001)),
+    "c3": ("brdf-row.toml", None, 960, 540, 4096, 1, 0, False, ()),
+    "c3p": ("brdf-row.toml", "phong", 960, 540, 4096, 1, 0, False, ()),
+    "c3b": ("brdf-row.toml", "blinn-phong", 960, 540, 4096, 1, 0, False, ()),
+    "c4": ("mesh-box.toml", None, 1920, 1370, 2048, 0, 0, True, ()),
+    "c5": ("ibl-lens.toml", None, 2048, 2048, 8192, 1, 0, True, ()),
+}
+
+
+def stated_tiles(w, h, rows=()):
+    """[(x0, y0, tw, th)]: disjoint; 8 x 8 scattered 16-px tiles + whole rows (a tile that a row crosses is dropped)."""
+    out = []
+    cw, ch = w // 8, h // 8
+    for j in range(8):
+        for i in range(8):
+            x0 = cw * i + (37 * j + 11 * i) % max(1, cw - 16)
+            y0 = ch * j + (29 * i + 17 * j) % max(1, ch - 16)
+            if any(y0 <= r < y0 + 16 for r in rows):
+                continue
+            out.append((x0, y0, 16, 16))
+    out += [(0, r, w, 1) for r in rows]
+    return out
+
+
+def tile_array(tl):
+    from lumillyrender_amd import abi
+    tiles = (abi.LrTile * len(tl))()
+    for k, (x, y, tw, th) in enumerate(tl):
+        tiles[k].x0, tiles[k].y0, tiles[k].w, tiles[k].h = x, y, tw, th
+    return tiles
+
+
+def tile_mask(w, h, tl):
+    m = np.zeros((h, w), dtype=bool)
+    for x, y, tw, th in tl:
+        assert not m[y:y + th, x:x + tw].any(), "tiles overlap"
+        m[y:y + th, x:x + tw] = True
+    return m
+
+
+def pack_tiles(img, tl):
+    """The tiles' pixels in tile order, rows of a tile top to bottom: (n_pix, 3)."""
+    return np.concatenate([img[y:y + th, x:x + tw].reshape(-1, 3) for x, y, tw, th in tl], axis=0)
+
+
+def stated_name(key):
+    return f"stated_{key}.npy"
+
+
 def film_name(case):
     name, edit, w, h, spp, integ, seed, _ = case
     tag = "" if edit is None else "_" + edit

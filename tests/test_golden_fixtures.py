@@ -26,7 +26,7 @@ def test_oracle_reproduces_the_film_crops(case):
     if gen and not gc.have_generated_assets():
         pytest.skip("generated assets missing (run __graft_entry__.build())")
     d = gc.load_scene(name, edit, w, h)
-    img = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.BRUTE)
+    img = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), mode=oracle.OWNBOX)
     ref = np.load(os.path.join(gc.GOLDEN, gc.film_name(case)))
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))          # bit for bit, NaNs included
     assert np.isfinite(ref).mean() > 0.99 and float(np.nanmax(ref)) > 0.0
@@ -66,7 +66,7 @@ def test_oracle_reproduces_the_function_vectors(fn):
     L = oracle.lib()
     desc = gc.load_scene("cbox-spheres.toml", None, 16, 16)
     o, d = gc.rays_in_box(512, (0, 0, -100), (556, 548, 560), 21)
-    prim, t = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    prim, t = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     assert np.array_equal(prim, fn["cbox_prim"]) and np.array_equal(t.view(np.uint32), fn["cbox_t"].view(np.uint32))
     assert (prim >= 12).any() and (prim < 12).any() and (prim < 0).any() or (prim >= 0).all()     # spheres and triangles are hit
     # the tree (reference-literal BVH mode, bvh.rs:131-141) returns what the definition returns
@@ -115,6 +115,6 @@ def test_oracle_reproduces_the_sky_and_mesh_vectors(fn):
     assert np.array_equal(oracle.sky_batch(desc, gc.sky_directions()).view(np.uint32), fn["sky_rgb"].view(np.uint32))
     desc = gc.load_scene("mesh-box.toml", None, 16, 16)
     o, d = gc.rays_at(**gc.MESH_RAYS)
-    prim, t = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    prim, t = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     assert np.array_equal(prim, fn["mesh_prim"]) and np.array_equal(t.view(np.uint32), fn["mesh_t"].view(np.uint32))
     assert (prim >= 0).mean() > 0.9 and len(np.unique(prim)) > 100

@@ -136,7 +136,7 @@ def test_closest_hit_matches_brute_force(dev, oracle, name):
     scene = dev.Scene(desc)
     o, d = _random_rays(desc, 20000, 3)
     gp, gt = scene.intersect(o, d)
-    op, ot = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    op, ot = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     assert np.array_equal(gp, op)
     assert np.array_equal(gt, ot)          # distances bit for bit
     assert (gp >= 0).mean() > 0.3
@@ -290,7 +290,7 @@ def test_mesh_scene_parity(dev, oracle, name, integ):
     params = desc.render_params(spp=8, seed=21, integrator=integ)
     scene = dev.Scene(desc)
     img = scene.render(params)
-    ref, ost = oracle.render(desc, params, mode=oracle.BVH, pad=0.05, with_stats=True)
+    ref, ost = oracle.render(desc, params, mode=oracle.OWNBOX_TREE, with_stats=True)
     st = scene.stats()
     assert (st.samples, st.segments, st.shadow_rays) == (ost.samples, ost.segments, ost.shadow_rays)
     if name == "ibl-lens.toml":
@@ -312,7 +312,7 @@ def test_mesh_closest_hit_matches_oracle(dev, oracle):
     d = tgt - o
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     gp, gt = scene.intersect(o, d)
-    op, ot = oracle.intersect(desc, o, d, mode=oracle.BVH, pad=0.05)
+    op, ot = oracle.intersect(desc, o, d, mode=oracle.OWNBOX_TREE)
     assert np.array_equal(gp, op) and np.array_equal(gt, ot)
     assert (gp < 100000).mean() > 0.3            # a good share of the hits are on the mesh itself
     scene.close()

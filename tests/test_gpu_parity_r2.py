@@ -119,7 +119,7 @@ def test_tree_equals_brute_force_on_ten_million_rays(dev, oracle):
     assert (bp >= 0).mean() > 0.9 and (bp < 100000).mean() > 0.2       # most rays hit; a good share hit the mesh itself
     # ... and the device's definition is the oracle's definition (BRUTE mode, plain loop over the primitives)
     m = 40_000
-    op, ot = oracle.intersect(desc, o[:m], d[:m], mode=oracle.BRUTE)
+    op, ot = oracle.intersect(desc, o[:m], d[:m], mode=oracle.OWNBOX)
     assert np.array_equal(bp[:m], op) and np.array_equal(bt[:m], ot)
     # the device-built LBVH prunes with different boxes: same answers
     lb = dev.Scene(desc, device_bvh=True)
@@ -157,7 +157,7 @@ def test_brute_force_kernel_on_flat_scenes(dev, oracle, name):
     o, d = _random_rays(desc, 200_000, 23)
     tp, tt = scene.intersect(o, d)
     bp, bt = scene.intersect(o, d, brute=True)
-    op, ot = oracle.intersect(desc, o, d, mode=oracle.BRUTE)
+    op, ot = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     assert np.array_equal(tp, bp) and np.array_equal(tt, bt)
     assert np.array_equal(bp, op) and np.array_equal(bt, ot)
     scene.close()
@@ -172,7 +172,7 @@ def test_mesh_film_against_brute_force_oracle(dev, oracle):
     params = desc.render_params(spp=2, seed=33)
     scene = dev.Scene(desc)
     img = scene.render(params)
-    ref, ost = oracle.render(desc, params, mode=oracle.BRUTE, with_stats=True)
+    ref, ost = oracle.render(desc, params, mode=oracle.OWNBOX, with_stats=True)
     st = scene.stats()
     assert (st.samples, st.segments, st.shadow_rays) == (ost.samples, ost.segments, ost.shadow_rays)
     assert float(np.max(np.abs(img - ref))) < TOL
@@ -184,8 +184,8 @@ def test_device_built_bvh_matches_the_oracle(dev, oracle, monkeypatch, capfd):
     LR_DEBUG makes lr_scene_create verify its own radix sort of the Morton codes (hand-written, four 8-bit passes)."""
     from lumillyrender_amd import abi
     monkeypatch.setenv("LR_DEBUG", "1")
-    for name, w, h, spp, mode, pad, flags in [("cbox-spheres.toml", 48, 40, 8, 0, 0.0, abi.LR_FLAG_STREAMING),
-                                              ("mesh-box.toml", 40, 30, 4, 1, 0.05, 0)]:
+    for name, w, h, spp, mode, pad, flags in [("cbox-spheres.toml", 48, 40, 8, oracle.OWNBOX, 0.0, abi.LR_FLAG_STREAMING),
+                                              ("mesh-box.toml", 40, 30, 4, oracle.OWNBOX_TREE, 0.0, 0)]:
         if name == "mesh-box.toml" and not _generated_assets():
             continue
         desc = load(name, w, h)

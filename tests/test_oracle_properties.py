@@ -306,3 +306,94 @@ def test_moller_trumbore_distance_error_bound():
     scale = 2.0 ** -24 * A * (np.linalg.norm(tv32.astype(np.float64), axis=1) + np.abs(t64)) / np.abs(det64)
     ratio = np.abs(t32.astype(np.float64) - t64)[ok32] / np.maximum(scale[ok32], 1e-300)
     assert float(ratio.max()) <= 7.5, float(ratio.max())                  # the first-order constant holds on every sample (observed maximum: 1.9); the product keeps 8
+
+
+# ---- round 6: the leaf's own box decides (bvh.rs:20-25), and the candidate order decides exact ties (bvh.rs:38-45,131-141) ----
+
+def _own_box_edge_rays(desc, n, seed):
+    """Rays aimed at faces, edges and corners of the primitives' own boxes (+- a few ulp), a third of them from the camera."""
+    rng = np.random.default_rng(seed)
+    d = desc.desc
+    pr = np.ctypeslib.as_array(C.cast(d.prims, C.POINTER(C.c_float)), (d.n_prims, C.sizeof(abi.LrPrimitive) // 4))
+    ty = pr[:, 0].view(np.int32)
+    # LrPrimitive = {type, material, v[9]} (include/lumilly_hip.h)
+    v = pr[:, 2:11].astype(np.float64).reshape(-1, 3, 3)
+    tri = (ty == 0)[:, None]
+    lo = np.where(tri, v.min(axis=1), v[:, 0] - v[:, 1, :1]); hi = np.where(tri, v.max(axis=1), v[:, 0] + v[:, 1, :1])
+    glo, ghi = lo.min(axis=0), hi.max(axis=0)
+    k = rng.integers(0, d.n_prims, n)
+    f = rng.random((n, 3))
+    snap = rng.integers(0, 3, (n, 3))
+    tgt = np.where(snap == 0, lo[k], np.where(snap == 1, hi[k], lo[k] + f * (hi[k] - lo[k])))
+    tgt = tgt * (1.0 + rng.integers(-3, 4, (n, 3)) * 6e-8)
+    cam = np.array(d.camera.aperture_position[:3], dtype=np.float64)
+    o = np.where(rng.random((n, 1)) < 0.3, cam[None, :], glo + rng.random((n, 3)) * (ghi - glo))
+    dirs = tgt - o
+    dirs /= np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-30)
+    return o.astype(np.float32), dirs.astype(np.float32)
+
+
+@pytest.mark.parametrize("name,n", [("cbox-spheres.toml", 400_000), ("brdf-row.toml", 400_000), ("two-spheres.toml", 100_000), ("mesh-box.toml", 12_000)])
+def test_own_box_definition_equals_the_literal_tree_walk(name, n):
+    """The reference's closest hit is tree-independent: min t over the primitives whose OWN exact box passes aabb.rs:74-92 and whose
+    own test accepts (mode OWNBOX, a loop over every primitive) == the literal SAH tree + collect-all-candidates walk (mode BVH,
+    pad 0) on rays aimed at the faces, edges and corners of the own boxes -- primitive and distance bits, exact ties included (both
+    take the first primitive of the candidate order): an inner node's box never rejects what the leaf's box accepts.  And the
+    box-free closest hit of rounds 1-5 (mode BRUTE) is NOT the same on such rays."""
+    from tests import golden_cases as gc
+    if name == "mesh-box.toml" and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    d = host.Description(scene_path(name)); d.set_resolution(16, 16)
+    o, dr = _own_box_edge_rays(d, n, 31)
+    p3, t3 = oracle.intersect(d, o, dr, mode=oracle.OWNBOX)
+    p1, t1 = oracle.intersect(d, o, dr, mode=oracle.BVH, pad=0.0)
+    assert np.array_equal(p1, p3) and np.array_equal(t1.view(np.uint32), t3.view(np.uint32))
+    if name != "two-spheres.toml":      # (its radius-1e5 sphere reports distances hundreds of units off its own box: the early out of the ordered walk needs a pad of that size there)
+        p5, t5 = oracle.intersect(d, o, dr, mode=oracle.OWNBOX_ORDERED, pad=0.05)
+        assert np.array_equal(p5, p3) and np.array_equal(t5.view(np.uint32), t3.view(np.uint32))
+    # ties by index: same distances, another primitive at exact ties only
+    p7, t7 = oracle.intersect(d, o, dr, mode=oracle.OWNBOX_INDEX)
+    p8, t8 = oracle.intersect(d, o, dr, mode=oracle.OWNBOX_TREE_INDEX)
+    assert np.array_equal(p7, p8) and np.array_equal(t7.view(np.uint32), t8.view(np.uint32))
+    assert np.array_equal(t7.view(np.uint32), t3.view(np.uint32))
+    if name in ("cbox-spheres.toml", "brdf-row.toml"):
+        p0, t0 = oracle.intersect(d, o, dr, mode=oracle.BRUTE)
+        differ = (t0.view(np.uint32) != t3.view(np.uint32)) | ((p0 < 0) != (p3 < 0))
+        assert differ.sum() > 50, int(differ.sum())
+        if name == "cbox-spheres.toml":
+            assert (p7 != p3).sum() > 0        # the edge rays do produce exact ties between different primitives
+
+
+def test_literal_render_is_audited_against_the_definition():
+    """mode BVH_AUDIT renders through the literal walk and answers every query by the definition as well: no query differs, by a tie
+    or otherwise (flat scenes: the definition's loop over every primitive; the mesh: its tie rule on the walk's candidate list)."""
+    from tests import golden_cases as gc
+    cases = [("cbox-spheres.toml", 40, 40, 24, 1), ("brdf-row.toml", 48, 27, 16, 1)]
+    if gc.have_generated_assets():
+        cases.append(("mesh-box.toml", 24, 18, 4, 0))
+    for name, w, h, spp, integ in cases:
+        d = host.Description(scene_path(name)); d.set_resolution(w, h)
+        p = d.render_params(spp=spp, seed=2, integrator=integ)
+        a, st = oracle.render(d, p, mode=oracle.BVH_AUDIT, with_stats=True)
+        assert (st.tie_flips, st.order_dependent) == (0, 0), name
+        assert np.array_equal(a.view(np.uint32), oracle.render(d, p, mode=oracle.BVH, pad=0.0).view(np.uint32)), name
+        if name != "mesh-box.toml":
+            assert np.array_equal(a.view(np.uint32), oracle.render(d, p, mode=oracle.OWNBOX).view(np.uint32)), name
+        assert np.array_equal(a.view(np.uint32), oracle.render(d, p, mode=oracle.OWNBOX_ORDERED, pad=0.05, fast=True).view(np.uint32)), name
+
+
+def test_host_leaf_order_is_the_reference_candidate_order():
+    """lr_host_build_bvh's prim_order == the depth-first leaf order of the reference's SAH tree (bvh.rs:69-127 with stable sorts, as the
+    oracle builds it), for every max_leaf -- also inside leaves of several primitives.  lr_scene_create numbers the primitives by it,
+    which makes the kernels' "lowest id" tie rule bvh.rs:131-141's "first minimum of the candidate list"."""
+    from tests import golden_cases as gc
+    names = ["cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"] + (["mesh-box.toml", "ibl-lens.toml"] if gc.have_generated_assets() else [])
+    for name in names:
+        d = host.Description(scene_path(name))
+        n = d.desc.n_prims
+        ref = oracle.bvh_leaf_order(d)
+        assert sorted(ref.tolist()) == list(range(n))
+        assert np.array_equal(np.ctypeslib.as_array(d.desc.bvh_prim_order, (n,)), ref), name
+        for ml in (1, 2, 4, 7):
+            _, _, order, _ = host.build_bvh(d.desc.prims, n, ml)
+            assert np.array_equal(np.array(order[:n], dtype=np.int32), ref), (name, ml)

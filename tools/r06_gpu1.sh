@@ -1,0 +1,6 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06a
+timeout 1500 python -m pytest tests/test_gpu_own_box.py -x -q -k "edge_rays or live" 2>&1 | tail -25 > gpurun_out/r06a/own_box.log
+timeout 900 python tools/ab4.py "cbox-spheres.toml 1024 1024 1024;mesh-box.toml 1920 1370 512;ibl-lens.toml 2048 2048 512;brdf-row.toml 960 540 2048" 3 product build/v_r05.so > gpurun_out/r06a/ab.log 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_own_box.py 2>&1 | tail -25 > gpurun_out/r06a/suite.log
