@@ -38,8 +38,12 @@ The JSON line also carries
                  on a bounded sample of the same frame
   setup          scene load, host SAH build seconds (description.rs:67-73's "bvh construction"), lr_scene_create, upload ms, the
                  4-wide tree's node / no-culling counts -- what main.rs:139-144 lumps into `elapse`; never part of `value`
-  env_overrides  every LR_* variable set in the environment; variables that change the product path (PRODUCT_ENV) are REFUSED
-                 unless --allow-overrides
+  env_overrides  every LR_* variable set in the environment; the ones that select another library build (PRODUCT_ENV) are REFUSED
+                 unless --allow-overrides (the product library itself reads no LR_* switch: csrc/lr_knobs.h)
+  ranks          every rank's share of a frame as per-rank lists: device ms, dominant-kernel ms, read-back ms, barrier wait, rays, host
+                 BVH build -- what makes a multi-GPU run that falls short diagnosable
+  other_configs  c1 (BASELINE configs[0]: the CPU plumbing case -- the oracle's rate on the whole job, the GPU frame only checked
+                 against it), c3 / c3p / c3b (GGX / Phong / Blinn-Phong rows), c4, c5
 """
 import argparse
 import glob
@@ -64,6 +68,12 @@ PRIM_BYTES = 48.0
 
 CONFIGS = {
     # name: scene, W, H, spp, integrator (None = the scene file's), description for config.workload, metric text
+    "c1": ("cbox-spheres.toml", 256, 256, 16, 0, "BASELINE configs[0]: the reference's scenes/new-cbox.toml 256x256 16 spp pt -- its CPU-runnable plumbing case",
+           "Msamples/sec, new-cbox 256x256 16 spp pt (CPU plumbing case)"),
+    "c3p": ("brdf-row-phong.toml", 960, 540, 4096, None, "the reference's scenes/brdf.toml with the GGX row replaced by Phong lobes, alpha in {1, 5, 10, 20} (phong.rs:37-68); pt-direct",
+            "Msamples/sec (whole node), brdf 960x540 4096 spp, Phong row"),
+    "c3b": ("brdf-row-blinn-phong.toml", 960, 540, 4096, None, "the reference's scenes/brdf.toml with the GGX row replaced by Blinn-Phong lobes, alpha in {1, 5, 10, 20} (blinn_phong.rs:37-72); pt-direct",
+            "Msamples/sec (whole node), brdf 960x540 4096 spp, Blinn-Phong row"),
     "c2": ("cbox-spheres.toml", 1024, 1024, 1024, 1, "the reference's scenes/new-cbox.toml with authored Cornell meshes; pt-direct, Lambert only",
            "Msamples/sec (whole node), new-cbox 1024x1024 pt-direct"),
     "c3": ("brdf-row.toml", 960, 540, 4096, None, "the reference's scenes/brdf.toml; GGX row + Lambert, pt-direct",
@@ -73,13 +83,14 @@ CONFIGS = {
     "c5": ("ibl-lens.toml", 2048, 2048, 8192, None, "the reference's scenes/welcome-2018.toml class: thin lens, HDR IBL sky, GGX mesh; pt-direct",
            "Msamples/sec (whole node), welcome-2018-class 2048x2048 8192 spp IBL"),
 }
+CPU_ONLY_CONFIGS = ("c1",)           # BASELINE configs[0] is the reference's CPU plumbing case: no GPU value, no counter profile (c1_leg)
 # legs attached to a default run: (config, steps, warmup, spp or 0 = the stated spp).  Every leg runs at its STATED size, warm-up
 # frame included (buffers sized by the frame -- the chunk sums of a band, up to 2 x 1 GiB -- are allocated in the warm-up frame, not in the timed one)
-OTHER_LEGS = (("c3", 2, 1, 0), ("c4", 2, 1, 0), ("c5", 1, 1, 0))
-# LR_* environment variables that change WHAT the library runs (csrc/lumilly_hip.hip, device.py): a stale one in the shell would
-# silently change what this file measures, so they are recorded in the JSON line and refused unless --allow-overrides
-PRODUCT_ENV = ("LR_HIP_LIB", "LR_PIPELINE", "LR_STACK_LDS", "LR_DENSE", "LR_SORT", "LR_GROUPS", "LR_SHADE_ORDER", "LR_RES_BLOCK", "LR_MAXGROUP", "LR_DEVICE_BVH", "LR_SKY_FLOAT4", "LR_HOST_LIB",
-               "LR_ORACLE_LIB", "LR_TAPER", "LR_CHUNK_LEN", "LR_BAND_PIX", "LR_SUB_SHIFT", "LR_CULL_SLACK")      # (replaces the library the cpu_baseline leg times: oracle/binding.py)
+OTHER_LEGS = (("c3", 2, 1, 0), ("c3p", 2, 1, 0), ("c3b", 2, 1, 0), ("c4", 2, 1, 0), ("c5", 1, 1, 0))
+# LR_* environment variables that change WHAT is measured: only the library paths are left -- the product library reads no LR_*
+# switch since round 6 (csrc/lr_knobs.h: the diagnostic knobs exist in the knob build only, which LR_HIP_LIB would have to select).
+# They are recorded in the JSON line and refused unless --allow-overrides.
+PRODUCT_ENV = ("LR_HIP_LIB", "LR_HOST_LIB", "LR_ORACLE_LIB")      # (LR_ORACLE_LIB replaces the library the cpu_baseline leg times: oracle/binding.py)
 
 
 def parse():
@@ -87,7 +98,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json config (default c2 = configs[1], the headline)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json config (default c2 = configs[1], the headline; c3p / c3b = the Phong / Blinn-Phong rows of configs[2]; "
+                    "c1 = configs[0], the CPU plumbing case)")
     ap.add_argument("--scene", default=None, help="override the config's scene file")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -136,14 +148,14 @@ def cpu_baseline(desc, W, H, integ, cpu_seconds):
         _, st = oracle.render(desc, p, threads=cores, mode=mode, pad=pad, with_stats=True, fast=True)
         return st, spp
     st, spp = timed(oracle.BVH, 0.0)
-    st2, spp2 = timed(oracle.BVH_ORDERED, 0.05)
+    st2, spp2 = timed(oracle.OWNBOX_ORDERED, 0.05)
     return {
         "value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores,
         "hardware_threads": os.cpu_count() or cores, "kind": "port", "build": "g++ -O3 -mavx2 -ffp-contract=off (%s)" % os.path.relpath(oracle._FAST_PATH, ROOT),
         "sample": f"{W}x{H} frame at {spp} spp ({st.samples} samples, {st.seconds:.1f} s), oracle in reference-literal BVH mode "
                   "(collect every overlapped leaf, then min), one thread per usable core (affinity and cgroup quota)",
         "optimized": {"value": round(st2.samples / st2.seconds / 1e6, 3), "unit": "Msamples/s",
-                      "sample": f"{W}x{H} frame at {spp2} spp ({st2.seconds:.1f} s), ordered early-out traversal of the same tree, row tasks"},
+                      "sample": f"{W}x{H} frame at {spp2} spp ({st2.seconds:.1f} s), ordered early-out traversal of the same tree with the leaf's own-box test (same film bits), row tasks"},
     }
 
 
@@ -391,6 +403,35 @@ def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_overri
     return leg
 
 
+def c1_leg(abi, device, host, args):
+    """BASELINE configs[0] at its stated size (256 x 256, 16 spp, pt: 1.05 M samples): the reference's own CPU-runnable case, so its
+    line is the CPU's -- the oracle in both modes on the WHOLE job -- and the GPU renders the same frame only to be CHECKED against it
+    (per-pixel bar, equal counters); no GPU `value` is claimed for a 1-M-sample job."""
+    from oracle import binding as oracle
+    scene_file, W, H, spp, integ, what, metric = CONFIGS["c1"]
+    desc = host.Description(os.path.join(ROOT, "scenes", scene_file))
+    desc.set_resolution(W, H)
+    p = desc.render_params(spp=spp, seed=0, integrator=integ)
+    cores = usable_cores()
+    ref, st = oracle.render(desc, p, threads=cores, mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
+    _, st2 = oracle.render(desc, p, threads=cores, mode=oracle.OWNBOX_ORDERED, pad=0.05, with_stats=True, fast=True)
+    scene = device.Scene(desc, device=0)
+    img = scene.render(p)
+    gs = scene.stats()
+    scene.close()
+    err = float(np.nanmax(np.abs(img - ref) / np.maximum(1.0, np.abs(ref))))
+    return {
+        "metric": metric, "value": None, "unit": "Msamples/s",
+        "config": {"workload": f"c1: {scene_file} ({what})", "baseline_config": "c1", "width": W, "height": H, "spp": spp, "integrator": "pt"},
+        "cpu_baseline": {"value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                         "sample": f"the whole job: {W}x{H} at {spp} spp ({st.samples} samples, {st.seconds:.2f} s), oracle in reference-literal BVH mode",
+                         "optimized": {"value": round(st2.samples / st2.seconds / 1e6, 3), "unit": "Msamples/s",
+                                       "sample": f"the whole job, ordered early-out traversal with the leaf's own-box test ({st2.seconds:.2f} s)"}},
+        "gpu_check": {"linf_rel_vs_oracle": err, "within_1e-4": bool(err < 1e-4), "device_ms": round(float(gs.render_ms), 3),
+                      "counters_equal": (int(gs.samples), int(gs.segments), int(gs.shadow_rays)) == (int(st.samples), int(st.segments), int(st.shadow_rays))},
+    }
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -474,11 +515,17 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize(dev_index)
 
-    def step(i):
+    walls = {"call": 0.0, "wait": 0.0}                        # this rank's wall seconds inside lr_render / inside the per-frame barrier (timed steps only)
+
+    def step(i, timed=False):
         params = desc.render_params(spp=spp, seed=i, integrator=integ, flags=flags, path_slots=args.slots)
+        t_a = time.perf_counter()
         scene.render(params, tiles, n_tiles, out=canvas)      # blocks until this rank's tiles are in the (shared) host film
+        t_b = time.perf_counter()
         st = scene.stats()
         shared_film.collect()                                   # every rank's tiles are in the shared film; a barrier publishes it to rank 0
+        if timed:
+            walls["call"] += t_b - t_a; walls["wait"] += time.perf_counter() - t_b
         return st
 
     for i in range(args.warmup):
@@ -487,13 +534,26 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        add_stats(acc, step(i), abi)
+        add_stats(acc, step(i, True), abi)
     barrier()
     elapsed = time.perf_counter() - t0
     my_pixels = sum(tiles[i].w * tiles[i].h for i in range(n_tiles))
     assert acc["samples"] == my_pixels * spp * args.steps, f"device finished {acc['samples']} samples, expected {my_pixels * spp * args.steps}"
     rank_ms = [acc["render_ms"] / max(args.steps, 1)]
     rank_setup = [setup]
+    n_st = max(args.steps, 1)
+    dom_k = max(range(abi.LR_K_COUNT), key=lambda k: acc["kernel_ms"][k] / max(acc["kernel_timed"][k], 1) * acc["kernel_launches"][k])
+    # what one rank's frame consists of (main.rs:129-132: the reference drains a channel; here every rank renders, reads back and meets
+    # the others): per-step means of this rank
+    mine = {"render_ms": acc["render_ms"] / n_st,                                  # device work of lr_render (HIP events)
+            "dominant_kernel": abi.LR_KERNEL_NAMES[dom_k],
+            "dominant_kernel_ms": acc["kernel_ms"][dom_k] / max(acc["kernel_timed"][dom_k], 1) * (acc["kernel_launches"][dom_k] / n_st),
+            "render_call_ms": walls["call"] / n_st * 1e3,                          # wall time inside lr_render: launch + device work + read-back + scatter into the film
+            "readback_ms": max(walls["call"] / n_st * 1e3 - acc["render_ms"] / n_st, 0.0),
+            "barrier_wait_ms": walls["wait"] / n_st * 1e3,                         # waiting for the slowest rank of the frame
+            "host_bvh_build_s": setup["host_bvh_build_s"], "upload_ms": setup["upload_ms"],
+            "pixels": my_pixels, "rays": (acc["segments"] + acc["shadow"]) // n_st}
+    rank_rows = [mine]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -504,6 +564,9 @@ def main():
         all_setup = [None] * world
         dist.all_gather_object(all_setup, setup)
         rank_setup = all_setup
+        all_rows = [None] * world
+        dist.all_gather_object(all_rows, mine)
+        rank_rows = all_rows
 
     total_samples = float(W) * H * spp * args.steps
     value = total_samples / elapsed / 1e6
@@ -525,6 +588,9 @@ def main():
                 "path_slots": acc["path_slots"], "pipeline": PIPELINE_NAMES.get(acc["pipeline"], "?"),
             },
             "rank_render_ms": {"max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3)},
+            # every rank's share of a frame, one list entry per rank (per-step means over the timed steps): a SCALE run that falls short
+            # says where -- an uneven deal (rays), a slow device (render_ms at equal rays), the read-backs (readback_ms), or waiting
+            "ranks": {k: [round(r[k], 3) if isinstance(r[k], float) else r[k] for r in rank_rows] for k in mine},
             "barrier": barrier_kind,
             # setup costs, NOT part of `value` (the scene is resident before the timed region): rank 0's in full, every rank's upload beside it
             "setup": setup,
@@ -543,6 +609,10 @@ def main():
         if default_run and not args.no_other_configs:
             # the other BASELINE configs, AFTER the headline's timed region (they do not touch `value`)
             legs = {}
+            try:
+                legs["c1"] = c1_leg(abi, device, host, args)
+            except Exception as e:                                      # noqa: BLE001
+                legs["c1"] = {"error": f"{type(e).__name__}: {e}"}
             for cfg, steps, warmup, spp_o in OTHER_LEGS:
                 try:
                     legs[cfg] = other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_o, args, abi.LR_FLAG_PROFILE)

@@ -91,9 +91,10 @@ int  lr_host_tile_rank(int tile_i, int tile_j, int world);
 int  lr_host_tile_stride(int world);
 int  lr_host_default_tile(void);
 
-/* Barrier of `world` processes of one node on two zero-initialised uint32 words of memory they all map (the shared film of
- * bench.py / multigpu.SharedFilm: the counterpart of main.rs:129-132's channel drain across processes).  Everything a process
- * wrote before it arrived is visible to every process that leaves.  LR_EDEVICE after `timeout_s` without the others. */
+/* Barrier of `world` processes of one node on THREE zero-initialised uint32 words of memory they all map -- arrivals, round,
+ * broken -- (the shared film of bench.py / multigpu.SharedFilm: the counterpart of main.rs:129-132's channel drain across
+ * processes).  Everything a process wrote before it arrived is visible to every process that leaves.  LR_EDEVICE after
+ * `timeout_s` without the others; that marks the barrier broken, and every waiting or later call on it fails at once. */
 int  lr_host_shm_barrier(uint32_t* state, int world, double timeout_s);
 
 size_t      lr_host_sizeof(const char* struct_name);   /* ABI self-check for bindings */

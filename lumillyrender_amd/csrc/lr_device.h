@@ -68,7 +68,7 @@ struct DevScene {
   const float4* nodes;
   const float4* prims;
   const float4* shade;
-  const float4* pbox;                  // 2 rows per primitive id: its own exact box {min.xyz, -} {max.xyz, -} (bvh.rs:20-25 decides with it)
+  const float4* pbox;                  // 2 rows per primitive id: its own exact box {min.xyz, r^2 of a sphere} {max.xyz, -} (bvh.rs:20-25 decides with it)
   const float4* emit;
   const float4* texels;
   const uint32_t* texels_rgbe;         // non-null: the map as RGBE words r | g << 8 | b << 16 | e << 24 (e >= 10: every value normal or zero), texels unused

@@ -149,16 +149,16 @@ LR_DEV bool own_box_exact(float4 lo, float4 hi, V3 o, V3 d) {                   
 #undef LR_AXIS
   return true;
 }
-// true = own_box_exact(lo, hi, o, d) is certainly true.  (ix, iy, iz) = 1/d to 1 ulp (v_rcp_f32; the traversal's clamped
-// reciprocals qualify because directions with a component below 1e-18 are left undecided: there the literal test meets
-// inf and NaN, whose comparisons this form does not model).  The literal test's slab parameters are
-// fl(fl(plane - o) * fl(1/d)); the ones below share the exact difference and differ by < 2.5e-7 relative, the margin is
-// 2^-20 relative + 1e-30 absolute on each side of every comparison the literal test makes between DIFFERENT axes (its
-// own axis always passes by construction: t_min <= t_max after the swap).  Every comparison is written so that a NaN
-// gives "undecided".
+// true = own_box_exact(lo, hi, o, d) is certainly true.  (ix, iy, iz) = v_rcp_f32 of d's components: 1/d to 1 ulp, and +-inf for a
+// zero or denormal component -- the slab parameters of that axis are then +-inf (or NaN when o lies in one of its planes) and the
+// margin arithmetic below turns them into NaN: "undecided", which is where the literal test's own inf / NaN rules must speak.
+// (The traversal's clamped reciprocals do NOT qualify: their finite products would be compared.)  The literal test's slab
+// parameters are fl(fl(plane - o) * fl(1/d)); the ones below share the exact difference and differ by < 2.5e-7 relative, the
+// margin is 2^-20 relative + 1e-30 absolute on each side of every comparison the literal test makes between DIFFERENT axes (its
+// own axis always passes by construction: t_min <= t_max after the swap).  Every comparison is written so that a NaN gives
+// "undecided".
 LR_DEV bool own_box_surely(float4 lo, float4 hi, V3 o, V3 d, float ix, float iy, float iz) {
   const float g = 9.5367431640625e-7f;                                          // 2^-20
-  const bool dir_ok = bool(__builtin_fabsf(d.x) >= 1e-18f) & bool(__builtin_fabsf(d.y) >= 1e-18f) & bool(__builtin_fabsf(d.z) >= 1e-18f);
   float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
   float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
   float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
@@ -174,7 +174,27 @@ LR_DEV bool own_box_surely(float4 lo, float4 hi, V3 o, V3 d, float ix, float iy,
   const float hi5 = kInf * (1.0f - 2.0f * g);
   const bool ok = bool(nx <= __builtin_fminf(__builtin_fminf(fy, fz), hi5)) & bool(ny <= __builtin_fminf(__builtin_fminf(fx, fz), hi5)) &
                   bool(nz <= __builtin_fminf(__builtin_fminf(fx, fy), hi5)) & bool(__builtin_fminf(__builtin_fminf(fx, fy), fz) >= -hi5);
-  return dir_ok & ok;
+  return ok;
+}
+
+#ifndef LR_NO_SETTLE
+#define LR_NO_SETTLE 0                 // measurement only (tools/build_variant.sh): skip the own-box stage = the closest hit over ALL primitives of rounds 1-5
+#endif
+// The winner `prim` of an unfiltered search is NOT a candidate (lo, hi = its own box rows; prim < 0: nothing to settle): the
+// approximate test first (every lane, ~40 instructions); where it cannot tell -- the hit lies within ~1e-6 relative of a face of
+// its own box as seen along the ray: 1e-3 of the hits on unit-sized triangles, 1e-5 on walls -- the literal test of THIS primitive
+// (3 IEEE divisions, under the lane mask); only a winner that really fails (~1e-6 of the rays) sends its query to the literal re-trace.
+LR_DEV bool own_box_rejects(float4 lo, float4 hi, int prim, V3 o, V3 d, float ix, float iy, float iz) {
+#if LR_NO_SETTLE
+  return false;
+#endif
+  const bool unsure = bool(prim >= 0) & !own_box_surely(lo, hi, o, d, ix, iy, iz);
+  bool rejected = false;
+  if (unsure) rejected = !own_box_exact(lo, hi, o, d);
+  return rejected;
+}
+LR_DEV bool own_box_rejects(float4 lo, float4 hi, int prim, V3 o, V3 d) {
+  return own_box_rejects(lo, hi, prim, o, d, __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -367,8 +387,7 @@ template <bool SHADOW>
 LR_DEV void own_box_settle_tree(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
   const size_t pi = s.prim < 0 ? 0 : (size_t)s.prim;
   const float4 lo = sc.pbox[2 * pi], hi = sc.pbox[2 * pi + 1];
-  const bool unsure = bool(s.prim >= 0) & !own_box_surely(lo, hi, s.o, s.d, s.ix, s.iy, s.iz);
-  if (unsure) retrace_tree<SHADOW>(sc, s, stk_n);
+  if (own_box_rejects(lo, hi, s.prim, s.o, s.d)) retrace_tree<SHADOW>(sc, s, stk_n);
 }
 
 // A burst of traversal for the lanes with `go` set (while-while: the wave first descends inner nodes
@@ -509,21 +528,11 @@ LR_DEV void retrace_flat(const float4* __restrict__ prims, const float4* __restr
   }
   t_out = bt; prim_out = bp;
 }
-// the winner `prim` of an unfiltered search is NOT certainly a candidate (lo, hi = its own box rows; prim < 0: nothing to settle)
-#ifndef LR_NO_SETTLE
-#define LR_NO_SETTLE 0                 // measurement only (tools/build_variant.sh): skip the own-box stage = the closest hit over ALL primitives of rounds 1-5
-#endif
-LR_DEV bool own_box_unsure(float4 lo, float4 hi, int prim, V3 o, V3 d) {
-#if LR_NO_SETTLE
-  return false;
-#endif
-  return bool(prim >= 0) & !own_box_surely(lo, hi, o, d, __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-}
 // settle the winner of the unfiltered search (t, prim) of a flat scene: certainly a candidate, or the literal query
 LR_DEV void own_box_settle_flat(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n, V3 o, V3 d, float& t, int& prim) {
   const int pi = prim < 0 ? 0 : prim;
   const float4 lo = pbox[2 * pi], hi = pbox[2 * pi + 1];
-  if (own_box_unsure(lo, hi, prim, o, d)) retrace_flat(prims, pbox, n, o, d, t, prim);
+  if (own_box_rejects(lo, hi, prim, o, d)) retrace_flat(prims, pbox, n, o, d, t, prim);
 }
 // scene.rs:127-131 on the settled closest hit of a connection: nearer than the window = occluded, beyond it = no hit
 LR_DEV void shadow_window(float dist, float t, int& prim, bool& occluded) {

@@ -24,6 +24,7 @@
 
 #include "../../include/lumilly_hip.h"
 #include "lr_lbvh.h"
+#include "lr_knobs.h"
 
 namespace lr {
 namespace {
@@ -564,7 +565,7 @@ int lbvh_build(const LrPrimitive* host_prims, int n, const float* extra_point, h
       std::fprintf(stderr, "[lr] lbvh: radix sort of %d codes verified\n", n);
     }
   }
-  const char* which = std::getenv("LR_DEVICE_BVH");
+  const char* which = lr_knob("LR_DEVICE_BVH");
   if (!(which && std::strcmp(which, "lbvh") == 0)) {
     // ---- PLOC over the sorted primitives (default) ----
     const size_t nn1 = (size_t)n;

@@ -205,6 +205,8 @@ struct PathCtl {
   bool finished;                       // the sample in rad ended (its radiance is complete)
   bool fresh;                          // no work item yet
   bool pend;                           // k_path_tree: the connection's walk is over, its outcome is parked in LDS until the next vertex
+  bool lit;                            // k_path_tree: the lane repeats its walk(s) LITERALLY -- own_box_exact behind every primitive test (bvh.rs:20-25) --
+                                       // because the own box of what the first walk found rejected the ray (~1e-6 of the rays)
 };
 
 #ifndef LR_PATH_WAVES
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   ls.emit = (const LdsRow*)s_emit;
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
-  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false;
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false; c.lit = false;
   uint32_t sq = 0;                                                   // the lane's queue of spares (sq_count / sq_head)
   LR_DIAG_ONLY(PathDiag dg = {}; const unsigned long long tq0 = __builtin_amdgcn_s_memtime(); unsigned long long tq;)
   LR_TL(st, 0)
@@ -486,9 +488,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
         // bvh.rs:20-25: the own box of each winner has the last word (lr_kernels.h own_box_surely); box rows from LDS
         {
           const int pa = h.prim < 0 ? 0 : h.prim, pb = h.sprim < 0 ? 0 : h.sprim;
-          const bool ua = own_box_unsure(rec(pa, 4), rec(pa, 5), h.prim, o, d);
-          const bool ub = own_box_unsure(rec(pb, 4), rec(pb, 5), h.sprim, o, sd);
-          if (ua | ub) {                                             // cold: ~1e-5 of the rays
+          const bool ua = own_box_rejects(rec(pa, 4), rec(pa, 5), h.prim, o, d);
+          const bool ub = own_box_rejects(rec(pb, 4), rec(pb, 5), h.sprim, o, sd);
+          if (ua | ub) {                                             // cold: ~1e-6 of the rays
 #pragma unroll 1
             for (int w = 0; w < 2; ++w) {
               if (w ? ub : ua) {
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       } else {
         TraceResult r = traverse_flat_raw<false>(flat_prims, sc.n_flat, o, d, 0.0f);
         const int pa = r.prim < 0 ? 0 : r.prim;
-        if (own_box_unsure(rec(pa, 4), rec(pa, 5), r.prim, o, d)) retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, d, r.t, r.prim);
+        if (own_box_rejects(rec(pa, 4), rec(pa, 5), r.prim, o, d)) retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, d, r.t, r.prim);
         t = r.t; prim = r.prim;
       }
     }
@@ -646,9 +648,10 @@ LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
 }
 // one primitive of a leaf against the lane's ray; true = a connection found its occluder (the walk is over)
-// LITERAL (ptrav_settle's re-trace): a primitive whose own test accepts counts only if aabb.rs:74-92 passes on its own box (bvh.rs:20-25)
-template <bool CONN, bool LITERAL, class LS>
-LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
+// lit (PathCtl::lit, almost never set: a wave-level skip): a primitive whose own test accepts counts only if aabb.rs:74-92 passes on
+// its own box (bvh.rs:20-25)
+template <bool CONN, class LS>
+LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bool lit, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
   uint32_t idw = __float_as_uint(q0.w);
   int id = (int)(idw & 0x7fffffffu);
   float t; bool hit;
@@ -660,7 +663,7 @@ LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, V3
   else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
 #endif
   if (!hit) return false;
-  if (LITERAL && !own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], o, d)) return false;
+  if (lit) { if (!own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], o, d)) return false; }
   if (CONN && conn) {
     float diff = t - ls.sh_d.v.w;
     if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return true; }   // (the occluder: ptrav_settle looks at its own box)
@@ -675,8 +678,8 @@ LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, V3
 #ifndef LR_LEAF_UNROLL2
 #define LR_LEAF_UNROLL2 1
 #endif
-template <bool CONN, bool LITERAL = false, class LS>
-LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, const uint32_t* stk_n) {
+template <bool CONN, class LS>
+LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bool lit, const uint32_t* stk_n) {
   const V3 o = v3(ls.ray_o.v), d = ptrav_dir<CONN>(conn, ls);
   uint32_t enc = (uint32_t)~s.cur;
   uint32_t first = enc >> 3, count = enc & 7u;
@@ -686,11 +689,11 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
   for (uint32_t k = 0; ; k += 2) {
     const bool more1 = k + 1 < count;
     if (more1) { b0 = q[3 * k + 3]; b1 = q[3 * k + 4]; b2 = q[3 * k + 5]; }
-    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, a0, a1, a2)) return false;
+    if (ptrav_prim<CONN>(sc, s, ls, conn, lit, o, d, a0, a1, a2)) return false;
     if (!more1) break;
     const bool more2 = k + 2 < count;
     if (more2) { a0 = q[3 * k + 6]; a1 = q[3 * k + 7]; a2 = q[3 * k + 8]; }
-    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, b0, b1, b2)) return false;
+    if (ptrav_prim<CONN>(sc, s, ls, conn, lit, o, d, b0, b1, b2)) return false;
     if (!more2) break;
   }
 #else
@@ -698,7 +701,7 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
   for (uint32_t k = 0; k < count; ++k) {
     float4 q0 = n0, q1 = n1, q2 = n2;
     if (k + 1 < count) { n0 = q[3 * k + 3]; n1 = q[3 * k + 4]; n2 = q[3 * k + 5]; }
-    if (ptrav_prim<CONN, LITERAL>(sc, s, ls, conn, o, d, q0, q1, q2)) return false;
+    if (ptrav_prim<CONN>(sc, s, ls, conn, lit, o, d, q0, q1, q2)) return false;
   }
 #endif
   return ptrav_pop(sc, s, stk_n);
@@ -712,7 +715,7 @@ LR_DEV bool ptrav_leaf(const DevScene& sc, PTrav& s, const LS& ls, bool conn, co
 #define LR_BURST_NEE 3
 #endif
 template <bool CONN, class LS>
-LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
+LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bool lit, uint32_t* stk_n, bool& go, PathDiag* dg = nullptr) {
   (void)dg;
 #if LR_PRIO_ANY
   LR_SETPRIO(LR_PRIO_NODE);
@@ -738,25 +741,14 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, u
 #if LR_PRIO_ANY
   if (LR_PRIO_LEAF != LR_PRIO_NODE) LR_SETPRIO(LR_PRIO_LEAF);
 #endif
-  if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, ls, conn, stk_n);
+  if (go && s.cur < 0) go = ptrav_leaf<CONN>(sc, s, ls, conn, lit, stk_n);
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
-// The literal walk of (ray_o, conn ? sh_d : ray_d) for a lane whose winner is not certainly a candidate under bvh.rs:20-25
-// (lr_kernels.h own_box_surely): the same tree -- its padded boxes contain every primitive's own box -- with own_box_exact behind
-// every primitive test.  Cold (~1e-5 of the rays); the lane's traversal stack is free, its walk being over.
-// LR_SETTLE_PRELOAD: the vertex's shading rows travel with the box rows of the settle stage (one round trip, 16 more live registers)
-#ifndef LR_SETTLE_PRELOAD
-#define LR_SETTLE_PRELOAD 0
+// 1: the distance of what a parked connection reached is parked with it (1 KB of LDS more per workgroup); 0: re-derived where needed
+#ifndef LR_PARK_T
+#define LR_PARK_T 0
 #endif
-template <bool CONN, class LS>
-LR_DEV void ptrav_retrace(const DevScene& sc, const LS& ls, bool conn, uint32_t* stk_n, float& t, int& prim, bool& occluded) {
-  PTrav s; ptrav_begin(s, ptrav_dir<CONN>(conn, ls));
-  bool go = true;
-#pragma unroll 1
-  while (go) go = s.cur >= 0 ? ptrav_node<CONN>(sc, s, ls, conn, stk_n) : ptrav_leaf<CONN, true>(sc, s, ls, conn, stk_n);
-  t = s.t; prim = s.prim; occluded = s.occluded;
-}
 // the outcome of a connection's walk in one word: 0 = nothing in the window, w + 1 = primitive w hit inside it, -(x + 1) = occluded by x
 LR_DEV uint32_t conn_word(const PTrav& s) { return s.prim < 0 ? 0u : (s.occluded ? (uint32_t)-(s.prim + 1) : (uint32_t)(s.prim + 1)); }
 
@@ -782,7 +774,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   __shared__ RowVec s_emit[NEE ? kEmitLds * 3 : 1];
-  __shared__ uint32_t s_conn[NEE ? kBlock : 1];                      // conn_word of the lane's parked connection (PathCtl::pend)
+  __shared__ uint32_t s_conn[NEE ? (1 + LR_PARK_T) * kBlock : 1];    // the lane's parked connection (PathCtl::pend): conn_word [, the distance of what it reached]
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
@@ -801,7 +793,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   ls.emit = emit_lds ? (const LdsRow*)s_emit : nullptr;
   ls.ray_o.v = make_float4(0, 0, 0, __int_as_float(-1));
   ls.ray_d.v = ls.thr.v = ls.rad.v = ls.sh_d.v = ls.sh_w.v = make_float4(0, 0, 0, 0);
-  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false;
+  PathCtl c; c.has_sh = false; c.finished = false; c.fresh = true; c.pend = false; c.lit = false;
   PTrav tr; ptrav_begin(tr, v3(1.0f, 0.0f, 0.0f));
   bool go = false;                                                   // the lane's walk is under way
   uint32_t sq = 0;                                                   // the lane's queue of one spare
@@ -810,14 +802,14 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   while (true) {
     // ================= retire point (converged) =================
     // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, the spare count, has_sh, occluded.)
-    // (a) connections whose walk is over: the outcome is PARKED (one word in LDS) and the lane starts its continuation ray.  It is
+    // (a) connections whose walk is over: the outcome is PARKED (two words in LDS) and the lane starts its continuation ray.  It is
     // settled and resolved (scene.rs:127-147) at the lane's next vertex, where the wave's finished rays are densest: resolving the
     // one or two connections that end per burst on the spot ran ~70 instructions at 1-3 lanes, and the own-box test (bvh.rs:20-25)
     // would have doubled that.  The radiance still receives the connection before anything the next vertex adds: same sums.
     if constexpr (NEE) {
       const bool fs = __float_as_int(ls.ray_o.v.w) >= 0 && !go && c.has_sh;
       if (fs) {
-        s_conn[threadIdx.x] = conn_word(tr);
+        s_conn[threadIdx.x] = conn_word(tr); if (LR_PARK_T) s_conn[kBlock + threadIdx.x] = __float_as_uint(tr.t);
         c.has_sh = false; c.pend = true;
         ptrav_begin(tr, v3(ls.ray_d.v));
         go = true;
@@ -827,77 +819,56 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     // connection's radiance, then the vertex
     const bool fm = __float_as_int(ls.ray_o.v.w) >= 0 && !go;         // (a) left only closest-hit walks among these
     if (__ballot(fm) != 0) {
-      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime();)
-      // ONE round trip for every row this stage reads: the hit's shading record and own box and -- pt-direct -- the own box, normal and
-      // emission of what the parked connection reached.  (Each dependent trip through the vector-memory path costs thousands of
-      // cycles under the walk's load.)
+      LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); if (!NEE) { dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(fm && tr.prim >= 0)); })
+      // ---- settle (lr_kernels.h own_box_rejects): is each winner a candidate under bvh.rs:20-25?  One round trip for the own-box
+      // rows of both.  A lane in literal mode has been through this: its walks tested every primitive's own box themselves ----
       const V3 o = v3(ls.ray_o.v);
-      bool hitv = fm && tr.prim >= 0;
-      size_t pr = hitv ? (size_t)tr.prim : 0;
-      float4 blo = row_now(sc.pbox + 2 * pr), bhi = row_now(sc.pbox + 2 * pr + 1);
-#if LR_SETTLE_PRELOAD
-      float4 r0 = row_now(sc.shade + 4 * pr), r1 = row_now(sc.shade + 4 * pr + 1), r2 = row_now(sc.shade + 4 * pr + 2), r3 = row_now(sc.shade + 4 * pr + 3);
-#endif
+      const bool chk = fm && !c.lit;
+      const bool hitv = chk && tr.prim >= 0;
+      const size_t pr = hitv ? (size_t)tr.prim : 0;
+      const float4 blo = sc.pbox[2 * pr], bhi = sc.pbox[2 * pr + 1];
       bool pm = false, cocc = false; int cp = -1; float ct = 0.0f;
-      float4 clo = blo, chi = bhi, csh = blo, cem = bhi;
+      bool uc = false;
       if constexpr (NEE) {
         pm = fm && c.pend;
         LR_DIAG_ONLY(dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(pm));)
-        if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; }
+        if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; if (LR_PARK_T) ct = __uint_as_float(s_conn[kBlock + threadIdx.x]); }
         const size_t pc = cp >= 0 ? (size_t)cp : 0;
-        clo = row_now(sc.pbox + 2 * pc); chi = row_now(sc.pbox + 2 * pc + 1); csh = row_now(sc.shade + 4 * pc); cem = row_now(sc.shade + 4 * pc + 2);
+        const float4 clo = sc.pbox[2 * pc], chi = sc.pbox[2 * pc + 1];
+        uc = own_box_rejects(clo, chi, (pm && chk) ? cp : -1, o, v3(ls.sh_d.v));
       }
-      // settle (lr_kernels.h own_box_surely): is each winner certainly a candidate?
-#if LR_NO_SETTLE
-      bool ur = false, uc = false;
-#else
-      bool ur = hitv & !own_box_surely(blo, bhi, o, v3(ls.ray_d.v), tr.ix, tr.iy, tr.iz);
-      bool uc = false;
-      if constexpr (NEE) uc = own_box_unsure(clo, chi, cp, o, v3(ls.sh_d.v));
-#endif
-      if (ur | uc) {                                                 // cold: the literal walk, then the rows of what it found
-        bool dummy = false;
-        if constexpr (NEE) {
-#pragma unroll 1
-          for (int it = 0; it < 2; ++it) {                           // (one copy of the walk)
-            const bool conn = it == 0;
-            if (conn ? uc : ur) {
-              float t_ = 0.0f; int p_ = -1; bool o_ = false;
-              ptrav_retrace<true>(sc, ls, conn, stk_n, t_, p_, o_);
-              if (conn) { ct = t_; cp = p_; cocc = o_; } else { tr.t = t_; tr.prim = p_; }
-            }
-          }
-          const size_t pc = cp >= 0 ? (size_t)cp : 0;
-          csh = sc.shade[4 * pc]; cem = sc.shade[4 * pc + 2];
-        } else {
-          if (ur) ptrav_retrace<false>(sc, ls, false, stk_n, tr.t, tr.prim, dummy);
-        }
-        hitv = fm && tr.prim >= 0; pr = hitv ? (size_t)tr.prim : 0;
-#if LR_SETTLE_PRELOAD
-        r0 = sc.shade[4 * pr]; r1 = sc.shade[4 * pr + 1]; r2 = sc.shade[4 * pr + 2]; r3 = sc.shade[4 * pr + 3];
-#endif
-      }
+      const bool ur = own_box_rejects(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
+      // ---- the parked connection's radiance (scene.rs:127-147), unless its own box just rejected it ----
       if constexpr (NEE) {
-        if (__ballot(pm) != 0) {
-          if (pm) {
-            const V3 dir = v3(ls.sh_d.v);
-            // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives
-            // it again, the same bits (centre from the shading record, r^2 from the box rows)
-            if (cp >= 0 && !cocc && (__float_as_uint(csh.w) >> 31)) { const V3 co = o - v3(csh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, dir, &ct); }
-            auto crec = [&](int, int row) -> float4 { return row == 0 ? csh : cem; };
-            V3 L = path_shadow_resolve(v3(ls.rad.v), o, dir, v3(ls.sh_w.v), cocc, cp, ct, crec);
+        const bool rm = pm && !uc;
+        if (__ballot(rm) != 0) {
+          if (rm) {
+#if !LR_PARK_T
+            // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives it
+            // again, the same bits (centre from the shading record, r^2 from the box rows)
+            if (cp >= 0 && !cocc) {
+              const float4 sh = rec(cp, 0);
+              if (__float_as_uint(sh.w) >> 31) { const V3 co = o - v3(sh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, v3(ls.sh_d.v), &ct); }
+            }
+#endif
+            V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, rec);
             ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
             c.pend = false;
           }
         }
       }
-      LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(fm));)
-#if LR_SETTLE_PRELOAD
-      auto prec = [&](int, int row) -> float4 { return row == 0 ? r0 : (row == 1 ? r1 : (row == 2 ? r2 : r3)); };
-      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, prec, s_stat);
-#else
-      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, fm, tr.t, tr.prim, rec, s_stat);
-#endif
+      // ---- a rejected winner (~1e-6 of the rays): the lane walks again among the others, LITERALLY (ptrav_prim tests every
+      // primitive's own box).  A rejected connection is walked first, the continuation ray after it as always ----
+      const bool redo = ur | uc;
+      if (redo) {
+        if (NEE && uc) { c.has_sh = true; c.pend = false; ptrav_begin(tr, v3(ls.sh_d.v)); }
+        else ptrav_begin(tr, v3(ls.ray_d.v));
+        c.lit = true; go = true;
+      }
+      const bool vm = fm && !redo;                                   // the lanes whose vertex runs now
+      LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(vm));)
+      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, vm, tr.t, tr.prim, rec, s_stat);
+      c.lit = c.lit && !vm;
       LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample
@@ -933,16 +904,16 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
 #endif
     do {
 #ifdef LR_DIAG
-      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, stk_n, go, &dg);
+      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, c.lit, stk_n, go, &dg);
 #else
-      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, stk_n, go);
+      ptrav_burst<NEE>(sc, tr, ls, NEE && c.has_sh, c.lit, stk_n, go);
 #endif
       if constexpr (NEE) {
         // a connection whose walk is over does not wait for the retire point: its outcome is parked and the lane walks on with the
         // continuation ray (see (a))
         const bool dc = live && !go && c.has_sh;
         if (dc) {
-          s_conn[threadIdx.x] = conn_word(tr);
+          s_conn[threadIdx.x] = conn_word(tr); if (LR_PARK_T) s_conn[kBlock + threadIdx.x] = __float_as_uint(tr.t);
           c.has_sh = false; c.pend = true;
           ptrav_begin(tr, v3(ls.ray_d.v));
           go = true;

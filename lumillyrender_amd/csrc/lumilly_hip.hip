@@ -19,6 +19,7 @@
 #include "lr_kernels.h"
 #include "lr_path.h"
 #include "lr_lbvh.h"
+#include "lr_knobs.h"
 
 // the flat-scene kernels are compiled in lr_flat.hip (their own scheduler switch, see there); this unit only launches them
 namespace lr {
@@ -156,6 +157,7 @@ struct Wide4Builder {
   // hold it is culled by distance -- the reference's rule for that subtree.  Replaces round 3's sliver flag (sin(phi) < 1/8: a
   // heuristic on the shape; the bound above covers slivers through |det| >= 1e-3 like every other triangle).
   const std::vector<float>* leaf_area = nullptr;
+  double cull_slack = kCullSlack;       // (pack_scene: the LR_CULL_SLACK knob of a diagnostic build, read once per scene)
   struct Cand { float lo[3], hi[3]; int ref; };
   static float area(const Cand& c) {
     float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
@@ -231,8 +233,7 @@ struct Wide4Builder {
     out[me * kNodeRows + 0] = make_float4(org[0], org[1], org[2], fb(ebits));
     out[me * kNodeRows + 1] = make_float4(fb(qlo[0]), fb(qlo[1]), fb(qlo[2]), fb(qhi[0]));
     // the culling slack of this node's children: lim = bound + kappa * diagonal + 2 kappa * t_far(child)  (finite: no inf - inf on the device)
-    double slack_k = kCullSlack;
-    if (const char* e = std::getenv("LR_CULL_SLACK")) slack_k = std::atof(e);          // diagnostic
+    const double slack_k = cull_slack;
     const double kappa = std::isfinite(amax) ? slack_k * 5.9604644775390625e-8 * (double)amax / 1.0e-3 : 1.0e12;
     const float k2 = (float)std::fmin(2.0 * kappa, 1.0e12), kd = (float)std::fmin(kappa * std::sqrt(diag2), 1.0e30);
     out[me * kNodeRows + 2] = make_float4(fb(qhi[1]), fb(qhi[2]), k2, kd);
@@ -448,7 +449,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     // A map that came out of an .hdr file holds Radiance RGBE values, c * 2^(e - 136) per channel with one e per texel (the `image`
     // crate's decode behind sky.rs:45-48).  Re-encode every texel and keep 4 B instead of 16 B where the decode gives back the
     // caller's bits; one texel that does not (a procedural float map, a negative or denormal value) keeps the whole map as float4.
-    bool rgbe_ok = !(std::getenv("LR_SKY_FLOAT4") && std::atoi(std::getenv("LR_SKY_FLOAT4")) == 1);
+    bool rgbe_ok = !(lr_knob("LR_SKY_FLOAT4") && std::atoi(lr_knob("LR_SKY_FLOAT4")) == 1);
     texels_rgbe.resize(rgbe_ok ? n : 0);
     for (size_t i = 0; i < n; ++i) {
       const float c[3] = {d.sky.texels[3 * i], d.sky.texels[3 * i + 1], d.sky.texels[3 * i + 2]};
@@ -505,6 +506,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     int need = 0;
     Wide4Builder w4{nodes, wide};
     w4.leaf_area = &leaf_area;
+    if (const char* e = lr_knob("LR_CULL_SLACK")) { const double v = std::atof(e); if (!(v >= 0.0)) fail(LR_EINVAL, "LR_CULL_SLACK must be >= 0"); w4.cull_slack = v; }
     w4.build(0, &need);
     if (need > 150) fail(LR_EUNSUPPORTED, "BVH too deep for the traversal stack");
     s.stack_depth = need + 1;
@@ -621,8 +623,8 @@ std::vector<uint32_t> chunk_schedule(uint32_t spp) {
   uint32_t L = (spp + n0 - 1) / n0;
   uint32_t level_sum = 0;
   uint32_t R = kTaperRepeat;
-  if (const char* e = std::getenv("LR_TAPER")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) R = (uint32_t)v; }            // diagnostic: chunks per taper level
-  if (const char* e = std::getenv("LR_CHUNK_LEN")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) L = std::min<uint32_t>((uint32_t)v, spp); }   // diagnostic: body chunk length
+  if (const char* e = lr_knob("LR_TAPER")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) R = (uint32_t)v; }            // diagnostic: chunks per taper level
+  if (const char* e = lr_knob("LR_CHUNK_LEN")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) L = std::min<uint32_t>((uint32_t)v, spp); }   // diagnostic: body chunk length
   for (uint32_t l = L / 2; l >= 1; l /= 2) level_sum += l;
   if (level_sum == 0) R = 0;
   else R = std::min<uint32_t>(R, spp / (2 * (level_sum + 1)));            // the taper takes at most half of the samples
@@ -663,7 +665,7 @@ struct Launcher {
 
 // LR_STACK_LDS=<n> (diagnostic): keep only n stack entries per lane in LDS so that tests reach the spill path
 int stack_lds_limit() {
-  if (const char* e = std::getenv("LR_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= kStackLdsMax) return v; }
+  if (const char* e = lr_knob("LR_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= kStackLdsMax) return v; }
   return kStackLdsMax;
 }
 
@@ -730,7 +732,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     const uint64_t want = ((uint64_t)n_pix * row_bytes + band_budget - 1) / band_budget;
     band_pix = (uint32_t)(((uint64_t)n_pix + want - 1) / want);
   }
-  if (const char* e = std::getenv("LR_BAND_PIX")) { long long v = std::atoll(e); if (v >= 1 && v < (long long)n_pix) band_pix = (uint32_t)v; }   // tests / diagnostics
+  if (const char* e = lr_knob("LR_BAND_PIX")) { long long v = std::atoll(e); if (v >= 1 && v < (long long)n_pix) band_pix = (uint32_t)v; }   // tests / diagnostics
   if (band_pix < n_pix) band_pix = (band_pix + 1023u) / 1024u * 1024u;
   const uint32_t n_bands = n_pix > 0 ? (n_pix + band_pix - 1) / band_pix : 1;
   uint64_t n_items64 = (uint64_t)std::min(band_pix, n_pix) * n_chunks;      // of one band (the last one may be smaller)
@@ -747,7 +749,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // lr_kernels.h kRSeg): measured +3.9 % on the BRDF row (four lists), but -2.5 % on the Lambert-only headline scene, where
   // there is little chunk waste to win and the 8-wave barriers cost more than they save
   bool big_block = s.dev.n_flat > 0 && n_lists >= 4 && (size_t)3 * (resident_lds_bytes(512, n_lists) + 512) <= 160 * 1024;
-  if (const char* e = std::getenv("LR_RES_BLOCK")) {                                       // diagnostic override
+  if (const char* e = lr_knob("LR_RES_BLOCK")) {                                       // diagnostic override
     if (std::atoi(e) == 256) big_block = false;
     if (std::atoi(e) == 512 && s.dev.n_flat > 0 && (size_t)3 * (resident_lds_bytes(512, n_lists) + 512) <= 160 * 1024) big_block = true;
   }
@@ -761,7 +763,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   {
     // default for flat scenes with ONE BSDF (the headline class: +10 % over the resident pipeline); with several
     // BSDFs in a wave the per-lane material dispatch loses to the resident pipeline's per-BSDF lists (brdf row: 7.8 vs 9.6 G/s)
-    const char* pe = std::getenv("LR_PIPELINE");
+    const char* pe = lr_knob("LR_PIPELINE");
     const bool forced = (rp_in.flags & LR_FLAG_FUSED) || (pe && std::strcmp(pe, "fused") == 0);
     if (s.dev.n_flat > 0 && !count && (forced || __builtin_popcount(present_mask) == 1)) fused = true;
     if (s.dev.n_flat == 0 && !count) fused = true;                       // tree scenes: k_path_tree (+56...68 % over the streaming pipeline)
@@ -799,7 +801,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
                    : only == 9u ? (nee_k ? (const void*)k_path_tree<9u, true> : (const void*)k_path_tree<9u, false>)
                                 : (nee_k ? (const void*)k_path_tree<31u, true> : (const void*)k_path_tree<31u, false>);
       want_waves = path_tree_waves(nee_k);
-      fused_stack = std::min(s.stack_depth, std::getenv("LR_STACK_LDS") ? stack_lds_limit() : kStackLdsFused);
+      fused_stack = std::min(s.stack_depth, lr_knob("LR_STACK_LDS") ? stack_lds_limit() : kStackLdsFused);
     }
     int fit = 0;
     hipFuncAttributes fa; HIP_OK(hipFuncGetAttributes(&fa, fused_kernel));
@@ -812,7 +814,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       // every CU waited for a slot: -6 %), the occupancy query rounds less
       const size_t granule = 1280, per_wg = (fa.sharedSizeBytes + fused_lds + granule - 1) / granule * granule;
       fit = std::min<int>(fit, (int)((160 * 1024) / std::max<size_t>(per_wg, granule)));
-      if (fit >= want_waves || fused_stack <= 8 || s.dev.n_flat > 0 || std::getenv("LR_STACK_LDS")) break;
+      if (fit >= want_waves || fused_stack <= 8 || s.dev.n_flat > 0 || lr_knob("LR_STACK_LDS")) break;
       --fused_stack;
     }
     if (fit < 1) fail(LR_EUNSUPPORTED, "the fused kernel does not fit a compute unit");
@@ -830,7 +832,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   s.acc.ensure(n_slots); s.sh_d.ensure(n_slots); s.sh_w.ensure(n_slots);
   // dense shading (k_shade_all): one launch per iteration over the slots themselves instead of one per class over lists;
   // then k_trace writes no lists and there is ONE shadow list per range (4 B per slot instead of 44)
-  const bool dense_shade = !resident && !(std::getenv("LR_DENSE") && std::atoi(std::getenv("LR_DENSE")) == 0);
+  const bool dense_shade = !resident && !(lr_knob("LR_DENSE") && std::atoi(lr_knob("LR_DENSE")) == 0);
   const size_t shadow_lists = dense_shade ? 1 : (size_t)(kNumShadeQueues - 1);
   s.q_shade.ensure(dense_shade ? 1 : (size_t)kNumShadeQueues * n_slots); s.c_shade.ensure((size_t)kNumShadeQueues * n_seg);
   s.q_shadow.ensure(shadow_lists * n_slots); s.c_shadow.ensure((size_t)(kNumShadeQueues - 1) * n_seg);
@@ -838,7 +840,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   // Ray sort before trace / shadow (lr_kernels.h "Ray sort"): measured on the 100k-triangle configs it LOSES 6 % (lanes per
   // VALU instruction 20.9 -> 23.0, but HBM fetch x3 and L2 hit rate 0.67 -> 0.54: the sorted order gathers 16-B rows from all
   // over the range), so it is opt-in: LR_SORT=1.  DESIGN.md section 6 has the numbers.
-  const bool sort_rays = !resident && s.dev.n_flat == 0 && std::getenv("LR_SORT") && std::atoi(std::getenv("LR_SORT")) == 1;
+  const bool sort_rays = !resident && s.dev.n_flat == 0 && lr_knob("LR_SORT") && std::atoi(lr_knob("LR_SORT")) == 1;
   if (sort_rays) { s.sort_key.ensure(n_slots); s.order.ensure(n_slots); }
   s.counters.ensure(4 + (size_t)n_bands);                                     // [0] dispenser (streaming), [1..3] retired slots per group, [4 + b] dispenser of band b
   s.stats_dev.ensure((size_t)kStatShards * kStatStride + 64);
@@ -859,7 +861,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
   ds.sh_d = s.sh_d.p; ds.sh_w = s.sh_w.p;
   ds.q_shade = s.q_shade.p; ds.c_shade = s.c_shade.p; ds.q_shadow = s.q_shadow.p; ds.c_shadow = s.c_shadow.p; ds.pool = s.pool.p;
   ds.sort_key = sort_rays ? s.sort_key.p : nullptr; ds.order = sort_rays ? s.order.p : nullptr;
-  const bool shade_ordered = !resident && !(std::getenv("LR_SHADE_ORDER") && std::atoi(std::getenv("LR_SHADE_ORDER")) == 0);
+  const bool shade_ordered = !resident && !(lr_knob("LR_SHADE_ORDER") && std::atoi(lr_knob("LR_SHADE_ORDER")) == 0);
   ds.shade_ordered = shade_ordered ? 1u : 0u;
   const size_t shade_lds = shade_ordered ? sizeof(ShadeOrderLds) : 0;
   ds.dense_shade = dense_shade ? 1u : 0u;
@@ -917,7 +919,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       // sub-bands of 2^17 pixel ranks inside the launch (DevState): the rays in flight stay within one strip of the film.  Config 5:
       // a rank's 1/8 share (524 k pixels spread over the whole film) 271 -> 257 ms, the whole frame -1.2 % (gpurun_out/r05g)
       uint32_t shift = s.dev.n_flat > 0 ? 0u : kSubBandShift;           // flat scenes have no locality to win (14 primitives in the scalar cache) and pay for the longer decode: config 3 +1.1 %
-      if (const char* e = std::getenv("LR_SUB_SHIFT")) { int v = std::atoi(e); if (v == 0 || (v >= 6 && v <= 30)) shift = (uint32_t)v; }   // diagnostic
+      if (const char* e = lr_knob("LR_SUB_SHIFT")) { int v = std::atoi(e); if (v == 0 || (v >= 6 && v <= 30)) shift = (uint32_t)v; }   // diagnostic
       ds.sub_shift = 0; ds.sub_last_item0 = 0; ds.sub_last_rank0 = 0; ds.sub_last_pix = bn;
       if (shift > 0 && shift < 31 && (bn >> shift) >= 2u) {
         const uint32_t full = (bn >> shift) - 1u;                            // the last sub-band takes the remainder too
@@ -974,7 +976,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
       // 100k-triangle pt scene, -3 % on the pt-direct one
       const bool has_shadow_stage = dp.integrator == LR_INTEGRATOR_PT_DIRECT && s.dev.n_emitters > 0;
       int G = (!count && n_seg >= 64) ? ((dense_shade && !has_shadow_stage && n_seg >= 96) ? 3 : 2) : 1;
-      if (const char* e = std::getenv("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
+      if (const char* e = lr_knob("LR_GROUPS")) { int v = std::atoi(e); if (v == 1 || ((v == 2 || v == 3) && n_seg >= (uint32_t)v)) G = v; }
       for (int g = 1; g < G; ++g) if (!s.gstream[g - 1]) HIP_OK(hipStreamCreateWithFlags(&s.gstream[g - 1], hipStreamNonBlocking));
       if (G > 1 && !s.grp_ev[0]) for (auto& e : s.grp_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       struct Group {
@@ -1001,7 +1003,7 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
         q.g_trace = grid_for(ktrace, s.n_cus, lds, q.n_seg * kBlock);
         q.g_shadow = grid_for(kshadow, s.n_cus, lds, q.n_seg * kBlock);
         uint32_t max_group = kMaxGroup;
-        if (const char* e = std::getenv("LR_MAXGROUP")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxGroup) max_group = (uint32_t)v; }   // diagnostic: shorter passes / smaller sort windows
+        if (const char* e = lr_knob("LR_MAXGROUP")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxGroup) max_group = (uint32_t)v; }   // diagnostic: shorter passes / smaller sort windows
         q.spb = std::min<uint32_t>(max_group, (q.n_seg + q.g_trace - 1) / q.g_trace);   // segments per workgroup pass; k_shade and k_shadow walk the same ranges
         q.ds.trace_spb = q.spb;
         q.g_gen = grid_for((const void*)k_generate, s.n_cus, 0, q.n_seg * kBlock);
@@ -1200,7 +1202,13 @@ const char* lr_last_error(void) { return g_err.c_str(); }
 #ifndef LR_BUILD_ID
 #define LR_BUILD_ID "unknown"          /* diagnostic variants (make diag / stamp / timeline) are not built through the id header */
 #endif
-const char* lr_build_info(void) { return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2 build=" LR_BUILD_ID; }
+const char* lr_build_info(void) {
+#ifdef LR_DIAG_KNOBS
+  return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2 knobs=on build=" LR_BUILD_ID;
+#else
+  return "lumilly_hip gfx950 wave64 -ffp-contract=off abi=2 knobs=off build=" LR_BUILD_ID;
+#endif
+}
 
 int lr_device_count(void) {
   int n = 0;

@@ -19,16 +19,26 @@ _LIB_PATH = os.environ.get("LR_HIP_LIB") or os.path.join(_HERE, "liblumilly_hip.
 _lib = None
 
 
+KNOBS_LIB_PATH = os.path.join(_HERE, "liblumilly_hip_knobs.so")      # `make -C lumillyrender_amd/csrc knobs`: the diagnostic knobs compiled in (csrc/lr_knobs.h)
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    _lib = load_library(_LIB_PATH)
+    return _lib
+
+
+def load_library(path):
+    """dlopen one build of the library and declare its entry points.  `lib()` is the process's product library; the tests load the
+    knob build beside it (tests/conftest.py) -- the product library reads no LR_* variable that changes what it runs."""
+    if not os.path.exists(path):
         raise ImportError(
-            f"{_LIB_PATH} is missing: the HIP extension was not built. Run "
+            f"{path} is missing: the HIP extension was not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C lumillyrender_amd/csrc`). "
             "There is no CPU fallback for the render path.")
-    l = C.CDLL(_LIB_PATH)
+    l = C.CDLL(path)
     vp = C.c_void_p
     fp = C.POINTER(C.c_float)
     l.lr_last_error.restype = C.c_char_p
@@ -57,7 +67,6 @@ def lib():
         l.lr_selftest_emission_sample.argtypes = [vp, C.c_int, fp, fp]
     if hasattr(l, "lr_selftest_rcp"):                      # diagnostics entry point; older builds (tools/sweep.sh) lack it
         l.lr_selftest_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-    _lib = l
     return l
 
 

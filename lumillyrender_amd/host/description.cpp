@@ -378,12 +378,22 @@ int lr_host_tiles(int width, int height, int tile, int rank, int world, LrTile* 
 }
 
 // Barrier of `world` processes on two words of shared memory (the film every rank of a node maps: multigpu.SharedFilm):
-// state[0] = arrivals of the current round, state[1] = round number.  Sense-reversing: the last arrival resets the count and
-// advances the round, the others spin on the round (pause, then yield, then sleep 50 us) until it moves or `timeout_s` runs out.
+// state[0] = arrivals of the current round, state[1] = round number, state[2] = broken.  Sense-reversing: the last arrival resets the
+// count and advances the round, the others spin on the round (pause, then yield, then sleep 50 us) until it moves or `timeout_s` runs
+// out.  A rank that times out marks the barrier BROKEN: every rank still waiting and every later call returns LR_EDEVICE at once --
+// a late rank must not complete the round alone and render into a film nobody is synchronised on.
 // Sequentially consistent atomics: everything a rank wrote into the film before it arrived is visible to every rank that leaves.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 int lr_host_shm_barrier(uint32_t* state, int world, double timeout_s) {
   if (!state || world <= 0) { set_last_error("bad barrier arguments"); return LR_EINVAL; }
   if (world == 1) return LR_OK;
+  if (__atomic_load_n(&state[2], __ATOMIC_SEQ_CST) != 0u) { set_last_error("shared-memory barrier is broken (a rank timed out on it earlier)"); return LR_EDEVICE; }
   const uint32_t round = __atomic_load_n(&state[1], __ATOMIC_SEQ_CST);
   if (__atomic_add_fetch(&state[0], 1u, __ATOMIC_SEQ_CST) == (uint32_t)world) {
     __atomic_store_n(&state[0], 0u, __ATOMIC_SEQ_CST);
@@ -393,11 +403,14 @@ int lr_host_shm_barrier(uint32_t* state, int world, double timeout_s) {
   const auto t0 = std::chrono::steady_clock::now();
   for (uint64_t spins = 0;; ++spins) {
     if (__atomic_load_n(&state[1], __ATOMIC_SEQ_CST) != round) return LR_OK;
-    if (spins < 2000) __builtin_ia32_pause();
+    if (spins < 2000) cpu_relax();
     else if (spins < 20000) std::this_thread::yield();
     else {
       std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (__atomic_load_n(&state[2], __ATOMIC_SEQ_CST) != 0u) { set_last_error("shared-memory barrier was broken by another rank's timeout"); return LR_EDEVICE; }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+        __atomic_store_n(&state[2], 1u, __ATOMIC_SEQ_CST);
+        if (__atomic_load_n(&state[1], __ATOMIC_SEQ_CST) != round) return LR_OK;      // (the round completed while this rank gave up: it stands; the flag stops the next one)
         set_last_error("shared-memory barrier timed out (a rank of the node did not arrive)");
         return LR_EDEVICE;
       }

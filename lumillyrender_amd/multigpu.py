@@ -91,7 +91,7 @@ def gather_tiles(film, width, height, tile, dist=None, dst=0, group=None):
     return film
 
 
-_BARRIER_WORDS = 16          # floats appended to the shared film file: 64 bytes, of which lr_host_shm_barrier uses two uint32 words
+_BARRIER_WORDS = 16          # floats appended to the shared film file: 64 bytes, of which lr_host_shm_barrier uses three uint32 words (arrivals, round, broken)
 
 
 class SharedFilm:
@@ -104,9 +104,11 @@ class SharedFilm:
     loop whose consumer only looks at the last frame (bench.py) may skip it.  The backing file is unlinked as soon as
     every rank has mapped it, so a crashed job leaves nothing in /dev/shm."""
 
-    def __init__(self, width, height, tile, dist=None, dst=0, group=None):
+    def __init__(self, width, height, tile, dist=None, dst=0, group=None, timeout_s=1800.0):
         import socket
         self.width, self.height, self.tile, self.dist, self.dst, self.group = width, height, tile, dist, dst, group
+        self.timeout_s = float(timeout_s)   # of one barrier (a frame, or dst's consume step between collect() and release()); gloo's own default is 30 min
+        self._state = None
         self.path = None                 # set only while the backing file still has a name (construction)
         self.name = None                 # the name it had, for diagnostics
         self.shared = False
@@ -117,8 +119,8 @@ class SharedFilm:
             dist.all_gather_object(hosts, socket.gethostname(), group=group)
             self.shared = len(set(hosts)) == 1 and os.path.isdir("/dev/shm")
         if self.shared:
-            n_film = height * width * 3
-            n_film += (-n_film) % 16                                  # the barrier words start on a 64-byte boundary
+            n_pix3 = height * width * 3
+            n_film = n_pix3 + (-n_pix3) % 16                          # the barrier words start on a 64-byte boundary behind the (padded) film
             box = [None]
             if rank == dst:
                 self.path = f"/dev/shm/lumilly_film_{os.getpid()}_{time.time_ns()}.f32"
@@ -129,7 +131,7 @@ class SharedFilm:
             if rank != dst:
                 self.path = box[0]
                 self._map = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(n_film + _BARRIER_WORDS,))
-            self.array = self._map[:n_film].reshape(height, width, 3)
+            self.array = self._map[:n_pix3].reshape(height, width, 3)
             self._state = self._map[n_film:].ctypes.data             # two uint32 words on a cache line of their own (lr_host_shm_barrier)
             self._world = world
             self.name = self.path
@@ -146,7 +148,9 @@ class SharedFilm:
     def _barrier(self):
         # the ranks of one node meet on two words of the shared film file itself (lr_host_shm_barrier): a gloo barrier of 8 processes
         # takes 0.3-0.6 ms, 2-3 % of a rank's 22-ms share of the headline frame; this one takes microseconds
-        host.shm_barrier(self._state, self._world)
+        if self._state is None:
+            raise RuntimeError("SharedFilm is closed")
+        host.shm_barrier(self._state, self._world, self.timeout_s)
 
     def collect(self):
         """After every rank rendered its tiles into `array`: the complete film is readable on dst."""
@@ -164,6 +168,7 @@ class SharedFilm:
     def close(self):
         if self.shared:
             self.dist.barrier(group=self.group)
+            self._state = None                                      # (points into the mapping that goes away below)
             arr, self.array, self._map = self.array, None, None
             del arr
             self.shared = False

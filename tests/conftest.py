@@ -24,3 +24,16 @@ def root():
 
 def scene_path(name):
     return os.path.join(ROOT, "scenes", name)
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    """The tests that steer the library with an LR_* variable (stack placement, banding, pipeline variants, builders) run on the KNOB
+    build: the product library compiles those variables out (csrc/lr_knobs.h).  Swaps the library behind lumillyrender_amd.device for
+    the duration of the test; scenes must be created and closed inside it."""
+    from lumillyrender_amd import device
+    klib = device.load_library(device.KNOBS_LIB_PATH)
+    assert b"knobs=on" in klib.lr_build_info()
+    assert "knobs=off" in device.build_info()
+    monkeypatch.setattr(device, "_lib", klib)
+    return monkeypatch

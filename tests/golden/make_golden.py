@@ -44,6 +44,22 @@ def stated_spp_films():
         print(path, img.shape, float(np.nanmean(img)), float(np.nanmax(img)))
 
 
+def stated_size_films():
+    """configs[0..4] (+ the Phong / Blinn-Phong rows) at their STATED film size and spp: the pixels of golden_cases.stated_tiles,
+    rendered through the oracle's reference-literal mode (SAH tree, collect-all-candidates walk, pad 0), packed in tile order."""
+    for key, (name, edit, w, h, spp, integ, seed, gen, rows) in gc.STATED_SIZE_CASES.items():
+        if gen and not gc.have_generated_assets():
+            print("skipped (generated assets missing):", gc.stated_name(key)); continue
+        d = gc.load_scene(name, edit, w, h)
+        tl = gc.stated_tiles(w, h, rows)
+        img, st = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), gc.tile_array(tl), len(tl), mode=oracle.BVH, pad=0.0,
+                                with_stats=True, fast=True)
+        packed = gc.pack_tiles(img, tl)
+        path = os.path.join(gc.GOLDEN, gc.stated_name(key))
+        np.save(path, packed)
+        print(path, packed.shape, float(np.nanmean(packed)), float(np.nanmax(packed)), f"{st.seconds:.1f} s")
+
+
 def functions():
     out = {}
     L = oracle.lib()
@@ -102,6 +118,12 @@ def functions():
 
 
 if __name__ == "__main__":
-    films()
-    stated_spp_films()
-    functions()
+    what = sys.argv[1:] or ["films", "stated_spp", "stated_size", "functions"]
+    if "films" in what:
+        films()
+    if "stated_spp" in what:
+        stated_spp_films()
+    if "stated_size" in what:
+        stated_size_films()
+    if "functions" in what:
+        functions()

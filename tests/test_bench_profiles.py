@@ -4,6 +4,8 @@ import importlib.util
 import json
 import os
 
+import pytest
+
 from tests.conftest import ROOT
 
 
@@ -71,6 +73,8 @@ def test_newest_profiles_were_taken_on_this_build():
     b = _bench()
     want_build = _tree_build_id()
     for cfg, (scene, w, h, spp, *_rest) in b.CONFIGS.items():
+        if cfg in b.CPU_ONLY_CONFIGS:
+            continue
         for kind in ("pmc", "traffic"):
             got = b.load_profile(kind, cfg, {"scene": scene, "width": w, "height": h, "spp": spp})
             assert got is not None, (cfg, kind)
@@ -78,19 +82,36 @@ def test_newest_profiles_were_taken_on_this_build():
 
 
 def test_bench_refuses_product_changing_environment(tmp_path):
-    """A stale LR_* variable in the shell would silently change what bench.py measures: variables that change
-    the product path are refused before anything touches the GPU, unless --allow-overrides; every LR_* variable is recorded."""
+    """A stale LR_* variable in the shell must not silently change what bench.py measures.  Since round 6 the
+    PRODUCT library reads no LR_* switch at all (csrc/lr_knobs.h: the knobs are compiled into the knob build only), so what is left to
+    refuse are the variables that select another library build; every LR_* variable is recorded."""
     import subprocess, sys
-    env = dict(os.environ, LR_PIPELINE="streaming")
+    env = dict(os.environ, LR_HIP_LIB=os.path.join(ROOT, "lumillyrender_amd", "liblumilly_hip_knobs.so"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
-    assert r.returncode != 0 and "LR_PIPELINE" in (r.stderr + r.stdout) and "--allow-overrides" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "LR_HIP_LIB" in (r.stderr + r.stdout) and "--allow-overrides" in (r.stderr + r.stdout)
     b = _bench()
-    assert {"LR_HIP_LIB", "LR_PIPELINE", "LR_SKY_FLOAT4", "LR_DEVICE_BVH", "LR_ORACLE_LIB"} <= set(b.PRODUCT_ENV)
-    # every variable the library reads with getenv is either a product switch bench.py knows about or LR_DEBUG (prints only)
+    assert set(b.PRODUCT_ENV) == {"LR_HIP_LIB", "LR_HOST_LIB", "LR_ORACLE_LIB"}
+    # the library sources: every LR_* variable is read through lr_knob() (compiled to "unset" in the product build) or is LR_DEBUG (prints only)
     import re
     src = ""
-    for f in ("lumillyrender_amd/csrc/lumilly_hip.hip", "lumillyrender_amd/csrc/lr_lbvh.hip", "lumillyrender_amd/device.py", "lumillyrender_amd/host.py",
-              "oracle/binding.py"):                                                            # (LR_ORACLE_LIB swaps the library cpu_baseline times)
+    for f in ("lumillyrender_amd/csrc/lumilly_hip.hip", "lumillyrender_amd/csrc/lr_lbvh.hip", "lumillyrender_amd/csrc/lr_kernels.h", "lumillyrender_amd/csrc/lr_path.h"):
         src += open(os.path.join(ROOT, f)).read()
-    read = set(re.findall(r'getenv\("(LR_[A-Z0-9_]+)"\)', src)) | set(re.findall(r'environ\.get\("(LR_[A-Z0-9_]+)"\)', src))
-    assert read - set(b.PRODUCT_ENV) <= {"LR_DEBUG"}, read - set(b.PRODUCT_ENV)
+    assert set(re.findall(r'getenv\("(LR_[A-Z0-9_]+)"\)', src)) <= {"LR_DEBUG"}
+    assert len(set(re.findall(r'lr_knob\("(LR_[A-Z0-9_]+)"\)', src))) >= 10
+    # ... and the python side reads library paths only
+    py = open(os.path.join(ROOT, "lumillyrender_amd/device.py")).read() + open(os.path.join(ROOT, "lumillyrender_amd/host.py")).read() + open(os.path.join(ROOT, "oracle/binding.py")).read()
+    assert set(re.findall(r'environ\.get\("(LR_[A-Z0-9_]+)"\)', py)) <= set(b.PRODUCT_ENV)
+
+
+def test_product_library_has_no_knob_strings():
+    """`strings liblumilly_hip.so | grep '^LR_'` is LR_DEBUG and nothing else; the knob build carries them."""
+    import re
+
+    def names(path):
+        return set(m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])(LR_[A-Z][A-Z0-9_]+)\x00", open(path, "rb").read()))
+    lib = os.path.join(ROOT, "lumillyrender_amd", "liblumilly_hip.so")
+    knob = os.path.join(ROOT, "lumillyrender_amd", "liblumilly_hip_knobs.so")
+    if not (os.path.exists(lib) and os.path.exists(knob)):
+        pytest.skip("libraries not built")
+    assert names(lib) <= {"LR_DEBUG"}, names(lib)
+    assert {"LR_PIPELINE", "LR_BAND_PIX", "LR_STACK_LDS", "LR_SUB_SHIFT"} <= names(knob)

@@ -118,3 +118,28 @@ def test_oracle_reproduces_the_sky_and_mesh_vectors(fn):
     prim, t = oracle.intersect(desc, o, d, mode=oracle.OWNBOX)
     assert np.array_equal(prim, fn["mesh_prim"]) and np.array_equal(t.view(np.uint32), fn["mesh_t"].view(np.uint32))
     assert (prim >= 0).mean() > 0.9 and len(np.unique(prim)) > 100
+
+
+@pytest.mark.parametrize("key", ["c1", "c2", "c3p"])
+def test_oracle_reproduces_the_stated_size_tiles(key):
+    """BASELINE configs at their stated FILM SIZE and spp (round 6): 64 scattered 16-px tiles of the full-size film (+ the rows through
+    the box's edges for configs[1]), through the reference-literal walk.  (c3, c3b, c4, c5 take 10-50 s each on 8 cores: the GPU suite
+    checks the device against all seven fixtures, and against the live oracle, tests/test_gpu_own_box.py.)"""
+    name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES[key]
+    d = gc.load_scene(name, edit, w, h)
+    tl = gc.stated_tiles(w, h, rows)
+    img, st = oracle.render(d, d.render_params(spp=spp, seed=seed, integrator=integ), gc.tile_array(tl), len(tl), mode=oracle.BVH, pad=0.0,
+                            with_stats=True, fast=True)
+    ref = np.load(os.path.join(gc.GOLDEN, gc.stated_name(key)))
+    got = gc.pack_tiles(img, tl)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert st.samples == len(ref) * spp and len(ref) >= 16384
+
+
+def test_stated_tiles_are_disjoint_and_inside_the_film():
+    for key, (name, edit, w, h, spp, integ, seed, gen, rows) in gc.STATED_SIZE_CASES.items():
+        tl = gc.stated_tiles(w, h, rows)
+        m = gc.tile_mask(w, h, tl)                       # (asserts disjointness)
+        assert int(m.sum()) >= 16384 and all(x >= 0 and y >= 0 and x + tw <= w and y + th <= h for x, y, tw, th in tl), key
+        for r in rows:
+            assert m[r].all(), (key, r)

@@ -455,9 +455,10 @@ def test_streaming_long_passes_lose_no_work(dev):
     scene.close(); scene2.close()
 
 
-def test_traversal_stack_spill_path(dev, oracle, monkeypatch):
+def test_traversal_stack_spill_path(dev, oracle, knobs):
     """The streaming kernels keep 31 stack entries per lane in LDS and the rest of the 4-wide tree's worst case in a
     spill buffer.  With LR_STACK_LDS=2 nearly every push goes through the spill path: same closest hits, same film."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     from lumillyrender_amd import abi
     desc = load("mesh-box.toml", 64, 48)
     scene = dev.Scene(desc)
@@ -615,7 +616,9 @@ def test_device_built_bvh_gives_the_same_film(dev, oracle, name):
         o, d = _random_rays(desc, 20000, 5)
     pa, ta = a.intersect(o, d)
     pb, tb = b.intersect(o, d)
-    assert np.array_equal(pa, pb) and np.array_equal(ta, tb)
+    # same distances; at an EXACT tie the host tree's scene follows the reference's candidate order and the device-built one the
+    # primitive index (round 6: without the reference's tree there is no reference order to follow)
+    assert np.array_equal(ta, tb) and (pa != pb).mean() < 1e-3
     a.close(); b.close()
 
 

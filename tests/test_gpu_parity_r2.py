@@ -124,7 +124,7 @@ def test_tree_equals_brute_force_on_ten_million_rays(dev, oracle):
     # the device-built LBVH prunes with different boxes: same answers
     lb = dev.Scene(desc, device_bvh=True)
     lp, lt = lb.intersect(o[:2_000_000], d[:2_000_000])
-    assert np.array_equal(lp, bp[:2_000_000]) and np.array_equal(lt, bt[:2_000_000])
+    assert np.array_equal(lt, bt[:2_000_000]) and (lp != bp[:2_000_000]).mean() < 1e-4      # (another primitive at exact ties only: index order vs the reference's candidate order)
     scene.close(); lb.close()
 
 
@@ -427,10 +427,11 @@ def test_two_rank_bench_assembles_the_single_rank_film(tmp_path, config):
 
 # ---- switches that must not change a film; boundary checks added in round 2 ----------------------------------------
 
-def test_sorted_and_unordered_variants_are_bit_identical(dev, monkeypatch):
+def test_sorted_and_unordered_variants_are_bit_identical(dev, knobs):
     """LR_DENSE=0 (per-class lists + one k_shade launch per class instead of k_shade_all over the slots), LR_SORT=1 (rays
     binned by octant / origin cell before trace and shadow), LR_SHADE_ORDER=0 (lists shaded in list order) and the number
     of slot groups only change which lane handles which ray or vertex: same films, same counters."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     if not _generated_assets():
         pytest.skip("generated assets missing")
     from lumillyrender_amd import abi
@@ -454,9 +455,10 @@ def test_sorted_and_unordered_variants_are_bit_identical(dev, monkeypatch):
         scene.close()
 
 
-def test_resident_workgroup_sizes_are_bit_identical(dev, oracle, monkeypatch):
+def test_resident_workgroup_sizes_are_bit_identical(dev, oracle, knobs):
     """The resident kernel runs 256- or 512-slot workgroups (the host picks 512 for flat scenes with several BSDF lists):
     slots, chunking and RNG keys do not depend on it, so the films are the same bits -- and match the oracle."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     from lumillyrender_amd import abi
     for name, integ in (("brdf-row.toml", 1), ("cbox-spheres.toml", 1), ("two-spheres.toml", None)):
         desc = load(name, 72, 40)

@@ -271,12 +271,13 @@ def test_bench_rccl_barrier_branch_runs(tmp_path):
 
 
 @pytest.mark.parametrize("builder", ["ploc", "lbvh"])
-def test_device_builders_prune_only(dev, oracle, monkeypatch, builder):
+def test_device_builders_prune_only(dev, oracle, knobs, builder):
     """the device builds the tree itself when the description carries none -- PLOC (default: bottom-up merging of
     Morton-ordered clusters, subtrees collapsed into leaves by SAH cost; within 2 % of the host SAH tree's render rate, 3 ms for
     10^5 triangles) or the round-1 Morton LBVH (LR_DEVICE_BVH=lbvh).  A tree only prunes: closest hits on random and grazing rays
     equal the device's brute force over all primitives, the film equals the host-tree film bit for bit, for a mesh, a handful
     of spheres, and the 2- and 3-primitive corner cases."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     if not _generated_assets():
         pytest.skip("generated assets missing (run __graft_entry__.build())")
     monkeypatch.setenv("LR_DEVICE_BVH", builder)

@@ -53,11 +53,12 @@ def _directions(rng, n):
 
 # ---- IBL texels as RGBE words --------------------------------------------------------------------------------------
 
-def test_ibl_map_is_stored_as_rgbe_and_decodes_to_the_same_bits(dev, oracle, monkeypatch):
+def test_ibl_map_is_stored_as_rgbe_and_decodes_to_the_same_bits(dev, oracle, knobs):
     """A map that was loaded from an .hdr file holds Radiance values c * 2^(e - 136) (the `image` crate's decode behind
     sky.rs:45-48); lr_scene_create re-encodes every texel, checks the device's decode of the whole map against the caller's
     floats and then keeps 4 B per texel instead of 16.  Same texel (sky.rs:57-78), same f32 bits: lookups equal the oracle's
     and the float4 build's bit for bit, films and counters of the two storage forms are identical."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     if not _generated_assets():
         pytest.skip("generated assets missing")
     desc = load("ibl-lens.toml", 64, 48)

@@ -171,12 +171,13 @@ def test_tile_deal_is_balanced_on_the_stated_films(dev, cfg):
                                                          ("brdf-row.toml", 1, ("default", "fused")),
                                                          ("mesh-box.toml", 0, ("default", "streaming")),
                                                          ("ibl-lens.toml", 1, ("default",))], ids=["cbox", "brdf", "mesh", "ibl"])
-def test_pixel_bands_give_the_same_film(dev, monkeypatch, scene_name, integ, flag_names):
+def test_pixel_bands_give_the_same_film(dev, knobs, scene_name, integ, flag_names):
     """A call whose chunk sums exceed 3 GiB is rendered in bands of consecutive pixel ranks, one launch each
     (Img::new is W x H whatever the spp, img.rs:13), and inside a launch the work items are dealt in sub-bands of 2^17 pixel ranks
     (the rays in flight stay within a strip of the film).  LR_BAND_PIX / LR_SUB_SHIFT force small bands and sub-bands on a small
     film: same film bits, same counters as the one-band render, in every pipeline -- including ragged last bands, a last sub-band
     that takes the remainder, and a tile list of several tiles."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
     from lumillyrender_amd import abi, host
     if scene_name in ("mesh-box.toml", "ibl-lens.toml") and not gc.have_generated_assets():
         pytest.skip("generated assets missing")
@@ -232,14 +233,14 @@ def test_config5_at_its_stated_size_stays_under_three_gigabytes(dev):
     scene.close()
 
 
-def test_lateral_residual_is_pinned(dev):
-    """What the culling slack cannot give back: a triangle accepted by triangle.rs:69-100 in f32 although the
-    ray's exact line MISSES it -- |det| barely above the absolute 1e-3 of triangle.rs:75, so the f32 barycentrics land in [0, 1] while
-    the float64 ones do not -- and misses its (padded) box too.  bvh.rs:131-141 would never test that leaf either when its OWN box test
-    (aabb.rs:74-92, exact boxes) fails, so this is a difference between brute force over all primitives and ANY box hierarchy, the
-    reference's included; it is pinned here on the three seeds of 2710 new ones that show it (fuzz_traversal seeds 1039, 6625, 6695:
-    one to four rays per tree, all in large-scale scenes seen edge-on): the brute-force hit lies outside its primitive's bounds,
-    its float64 barycentrics are outside the triangle, and the tree's answer is farther, never nearer."""
+def test_lateral_residual_is_closed_by_the_own_box(dev):
+    """Round 5 pinned a residual no box hierarchy could give back: a triangle accepted by triangle.rs:69-100 in f32 although the ray's
+    exact line MISSES it -- |det| barely above the absolute 1e-3 of triangle.rs:75, so the f32 barycentrics land in [0, 1] while the
+    float64 ones do not -- and misses its box too (fuzz_traversal seeds 1039, 6625, 6695: one to four rays per tree, large-scale scenes
+    seen edge-on).  The reference never reports such a hit: the leaf's OWN box test (bvh.rs:20-25, aabb.rs:74-92) fails.  With the
+    own box in the definition (round 6) the device's per-primitive evaluation of it and both trees agree on every ray of these seeds;
+    against the box-free closest hit of rounds 1-5 the same rays still differ, with a hit point outside its primitive's bounds,
+    float64 barycentrics outside the triangle and the tree's answer farther, never nearer."""
     if not gc.have_generated_assets():
         pytest.skip("generated assets missing")
     import importlib.util
@@ -247,6 +248,8 @@ def test_lateral_residual_is_pinned(dev):
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     for seed in (1039, 6625, 6695):
         rows, unexcused = fz.residual(seed)
+        assert unexcused == 0 and rows == [], (seed, rows)
+        rows, unexcused = fz.residual(seed, brute="all")
         assert unexcused == 0, seed
         assert 1 <= len(rows) <= 8, (seed, len(rows))
         for tree, ray, prim, u, v, cos, outside in rows:

@@ -62,7 +62,7 @@ def test_sharded_render_equals_single_rank(tmp_path, world, packed):
     assert np.array_equal(got, ref)
 
 
-def _shared_worker(rank, world, port, out_path):
+def _shared_worker(rank, world, port, out_path, W=W, H=H):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,6 +72,7 @@ def _shared_worker(rank, world, port, out_path):
     desc.set_resolution(W, H)
     params = desc.render_params(spp=SPP, seed=4)
     film = multigpu.SharedFilm(W, H, TILE, dist, dst=0)
+    assert film.array.shape == (H, W, 3)
     assert film.shared
     assert film.name and not os.path.exists(film.name)       # unlinked once every rank had mapped it: a crash leaks nothing
     tiles, n = multigpu.shard_tiles(W, H, TILE, rank, world)
@@ -92,12 +93,15 @@ def _shared_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_shared_memory_film(tmp_path, world):
+@pytest.mark.parametrize("world,film", [(2, (W, H)), (3, (W, H)), (8, (W, H)), (2, (37, 29))])
+def test_shared_memory_film(tmp_path, world, film):
     """bench.py's single-node path: every rank writes its tiles into one film in /dev/shm.  world = 8 is the node the
-    driver's scaling run uses (here the 40 x 28 film has six 16-pixel tiles: two of the eight ranks hold NO tile)."""
+    driver's scaling run uses (here the 40 x 28 film has six 16-pixel tiles: two of the eight ranks hold NO tile).  The 37 x 29
+    film has a float count that is not a multiple of 16: the barrier words sit behind a padded film (the film view
+    took the padded length and could not be reshaped)."""
+    W, H = film
     out_path = str(tmp_path / "film.npy")
-    mp.spawn(_shared_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    mp.spawn(_shared_worker, args=(world, _free_port(), out_path, W, H), nprocs=world, join=True)
     from lumillyrender_amd import host
     from oracle import binding as oracle
     desc = host.Description(scene_path("cbox-spheres.toml"))
@@ -199,4 +203,10 @@ def test_shared_memory_barrier(tmp_path):
     with pytest.raises(host.LumillyError):
         host.shm_barrier(m[48:].ctypes.data, 2, 0.2)                 # world 2, one arrival
     assert time.time() - t0 < 5.0
+    # ... and is BROKEN from then on: a late rank must not complete the round alone (every later call fails at once)
+    assert int(m[50]) == 1
+    t0 = time.time()
+    with pytest.raises(host.LumillyError):
+        host.shm_barrier(m[48:].ctypes.data, 2, 30.0)
+    assert time.time() - t0 < 1.0
     host.shm_barrier(m[48:].ctypes.data, 1, 0.2)                     # world 1: nothing to wait for

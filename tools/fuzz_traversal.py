@@ -136,8 +136,7 @@ def run(seed, n_rays=200_000):
     n_excused = [0]
     for lbvh in (False, True):
         scene = device.Scene(desc, device_bvh=lbvh)
-        if ref is None:
-            ref = scene.intersect(o, d, brute=True)
+        ref = scene.intersect(o, d, brute=True)           # the definition on THIS scene's numbering (exact ties: candidate order of the host tree / primitive index)
         tp, tt = scene.intersect(o, d)
         diff = (tp != ref[0]) | (tt != ref[1])
         idx = np.nonzero(diff)[0]
@@ -157,8 +156,8 @@ def run(seed, n_rays=200_000):
 RESIDUAL_SEEDS = (117, 122, 134, 137, 147, 179, 191, 197, 206, 208, 217, 268, 274, 282, 373, 496, 535, 542, 584, 693, 760, 770)
 
 
-def residual(seed, n_rays=200_000):
-    """The rays of one seed on which the tree (host SAH and device-built) differs from the device's brute force, each with the
+def residual(seed, n_rays=200_000, brute=True):
+    """The rays of one seed on which the tree (host SAH and device-built) differs from the device's brute force (`brute`: see device.Scene.intersect), each with the
     geometry of its BRUTE-FORCE hit in float64: barycentrics (u, v) of triangle.rs:76-88, |cos| between ray and triangle normal,
     and how far outside the triangle's own bounds the reported point o + t d lies (in units of the triangle's extent).
     Returns (rows, unexcused): rows = [(tree, ray, prim, u, v, |cos|, outside)], unexcused = differing rays whose brute-force hit is
@@ -171,8 +170,7 @@ def residual(seed, n_rays=200_000):
     rows, unexcused, ref = [], 0, None
     for lbvh in (False, True):
         scene = device.Scene(desc, device_bvh=lbvh)
-        if ref is None:
-            ref = scene.intersect(o, d, brute=True)
+        ref = scene.intersect(o, d, brute=brute)          # brute=True: every primitive behind its own exact box (the definition); "all": no box at all (rounds 1-5)
         tp, tt = scene.intersect(o, d)
         for i in np.nonzero((tp != ref[0]) | (tt != ref[1]))[0]:
             prim, t = int(ref[0][i]), float(ref[1][i])

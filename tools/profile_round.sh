@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag> [configs...]   (default: c2 c3 c4 c5)
+# usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag> [configs...]   (default: c2 c3 c3p c3b c4 c5)
 # Collects what DESIGN.md section 6 and bench.py's roofline blocks quote, into gpurun_out/<tag>/ (scratch); the exported
 # summaries land in gpurun_out/<tag>/profiles/<tag>_* and are copied into profiles/ (tracked) after the call:
 #   per config: full-size throughput (tools/quick_perf.py), rocprofv3 kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE
@@ -8,7 +8,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-CFGS=${*:-c2 c3 c4 c5}
+CFGS=${*:-c2 c3 c3p c3b c4 c5}
 OUT=$PWD/gpurun_out/$TAG
 PROF=$OUT/profiles
 mkdir -p "$OUT" "$PROF" profiles
@@ -50,6 +50,8 @@ for c in $CFGS; do
   case $c in
     c2) run_cfg c2 cbox-spheres.toml 1024 1024 1024 1024 10 ;;
     c3) run_cfg c3 brdf-row.toml 960 540 4096 4096 10 ;;
+    c3p) run_cfg c3p brdf-row-phong.toml 960 540 4096 4096 10 ;;
+    c3b) run_cfg c3b brdf-row-blinn-phong.toml 960 540 4096 4096 10 ;;
     c4) run_cfg c4 mesh-box.toml 1920 1370 2048 2048 3 ;;
     c5) run_cfg c5 ibl-lens.toml 2048 2048 8192 8192 2 ;;
   esac
