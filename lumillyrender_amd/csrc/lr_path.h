@@ -611,16 +611,24 @@ LR_DEV bool ptrav_node(const DevScene& sc, PTrav& s, const LS& ls, bool conn, ui
 #undef LR_SLAB
     int n_hit = (k0 < inf ? 1 : 0) + (k1 < inf ? 1 : 0) + (k2 < inf ? 1 : 0) + (k3 < inf ? 1 : 0);
     if (n_hit == 0) return ptrav_pop(sc, s, stk_n);
+#if LR_NODE_ORDER
+    nearest_then_slot_order(k0, k1, k2, k3, r0, r1, r2, r3);
+#else
     order2(k0, r0, k1, r1); order2(k2, r2, k3, r3); order2(k0, r0, k2, r2); order2(k1, r1, k3, r3); order2(k1, r1, k2, r2);
+#endif
 #if LR_PUSH_BRANCHFREE
     // the far children go on the stack far-first.  Entries at and above the new top are dead, so while three more fit the LDS
     // part every lane stores three words -- which ones is a select on n_hit -- instead of walking three blocks of predicated
     // stores with an LDS-or-spill branch in each (lanes of one wave differ in n_hit, so the wave used to walk them all)
     if (s.sp + 3 <= sc.stack_lds) {
       lds_u32* e = (lds_u32*)stk_n + s.sp * kBlock + threadIdx.x;
+#if LR_NODE_ORDER
+      e[0] = (uint32_t)r1; e[kBlock] = (uint32_t)r2; e[2 * kBlock] = (uint32_t)r3;      // hits first, in slot order: no select at all
+#else
       e[0] = (uint32_t)(n_hit == 4 ? r3 : (n_hit == 3 ? r2 : r1));
       e[kBlock] = (uint32_t)(n_hit == 4 ? r2 : r1);
       e[2 * kBlock] = (uint32_t)r1;
+#endif
     } else
 #endif
     if (n_hit == 4) { stack_store(sc, stk_n, s.sp, (uint32_t)r3); stack_store(sc, stk_n, s.sp + 1, (uint32_t)r2); stack_store(sc, stk_n, s.sp + 2, (uint32_t)r1); }
@@ -745,6 +753,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, b
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
+#ifndef LR_CONN_ROWS_EARLY
+#define LR_CONN_ROWS_EARLY 0           // 1: the normal and emission rows of what the parked connection reached are requested with the own-box rows
+#endif
 // 1: the distance of what a parked connection reached is parked with it (1 KB of LDS more per workgroup); 0: re-derived where needed
 #ifndef LR_PARK_T
 #define LR_PARK_T 0
@@ -829,12 +840,18 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
       const float4 blo = sc.pbox[2 * pr], bhi = sc.pbox[2 * pr + 1];
       bool pm = false, cocc = false; int cp = -1; float ct = 0.0f;
       bool uc = false;
+#if LR_CONN_ROWS_EARLY
+      float4 csh = blo, cem = bhi;
+#endif
       if constexpr (NEE) {
         pm = fm && c.pend;
         LR_DIAG_ONLY(dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(pm));)
         if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; if (LR_PARK_T) ct = __uint_as_float(s_conn[kBlock + threadIdx.x]); }
         const size_t pc = cp >= 0 ? (size_t)cp : 0;
         const float4 clo = sc.pbox[2 * pc], chi = sc.pbox[2 * pc + 1];
+#if LR_CONN_ROWS_EARLY
+        csh = row_now(sc.shade + 4 * pc); cem = row_now(sc.shade + 4 * pc + 2);    // (with the box rows: one round trip)
+#endif
         uc = own_box_rejects(clo, chi, (pm && chk) ? cp : -1, o, v3(ls.sh_d.v));
       }
       const bool ur = own_box_rejects(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
@@ -847,11 +864,20 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
             // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives it
             // again, the same bits (centre from the shading record, r^2 from the box rows)
             if (cp >= 0 && !cocc) {
+#if LR_CONN_ROWS_EARLY
+              const float4 sh = csh;
+#else
               const float4 sh = rec(cp, 0);
+#endif
               if (__float_as_uint(sh.w) >> 31) { const V3 co = o - v3(sh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, v3(ls.sh_d.v), &ct); }
             }
 #endif
+#if LR_CONN_ROWS_EARLY
+            auto crec = [&](int, int row) -> float4 { return row == 0 ? csh : cem; };
+            V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, crec);
+#else
             V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, rec);
+#endif
             ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
             c.pend = false;
           }

@@ -26,6 +26,20 @@ def scene_path(name):
     return os.path.join(ROOT, "scenes", name)
 
 
+@pytest.fixture(scope="module")
+def dev():
+    """The device binding (GPU suites).  There is no CPU fallback: without a GPU this fails."""
+    from lumillyrender_amd import device
+    assert device.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return device
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import binding
+    return binding
+
+
 @pytest.fixture
 def knobs(monkeypatch):
     """The tests that steer the library with an LR_* variable (stack placement, banding, pipeline variants, builders) run on the KNOB

@@ -1,6 +1,6 @@
 """What tests/golden/ holds and how it is produced -- shared by the generator (tests/golden/make_golden.py, runs the CPU oracle),
 the CPU suite (the oracle must still reproduce every fixture: tests/test_golden_fixtures.py) and the GPU suite (the HIP path must
-reproduce them WITHOUT the oracle: tests/test_gpu_parity_r4.py).
+reproduce them WITHOUT the oracle: tests/test_gpu_film.py, tests/test_gpu_math.py).
 
 Nothing can be captured from the reference itself (Rust, no toolchain, unseeded RNG: SURVEY 8c), so the vectors are the oracle's
 own output at fixed seeds.  A fixture survives an oracle edit that would move both sides of a live comparison together.

@@ -124,7 +124,7 @@ def test_oracle_reproduces_the_sky_and_mesh_vectors(fn):
 def test_oracle_reproduces_the_stated_size_tiles(key):
     """BASELINE configs at their stated FILM SIZE and spp (round 6): 64 scattered 16-px tiles of the full-size film (+ the rows through
     the box's edges for configs[1]), through the reference-literal walk.  (c3, c3b, c4, c5 take 10-50 s each on 8 cores: the GPU suite
-    checks the device against all seven fixtures, and against the live oracle, tests/test_gpu_own_box.py.)"""
+    checks the device against all seven fixtures, and against the live oracle, tests/test_gpu_film.py.)"""
     name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES[key]
     d = gc.load_scene(name, edit, w, h)
     tl = gc.stated_tiles(w, h, rows)

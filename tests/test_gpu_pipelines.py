@@ -1,53 +1,120 @@
-"""GPU parity, round 3: the fused pipeline (csrc/lr_path.h: one persistent launch, a lane carries its path) against the
-other two pipelines and the oracle; full-size count / tiling properties of BASELINE configs 3-5; the RCCL branch of
-bench.py."""
-import json
-import os
-import subprocess
-import sys
+"""GPU parity -- pipelines.
 
-import numpy as np
+The three pipelines (fused: a lane carries its path; resident: state in LDS; streaming: one launch per stage) and their variants give the same bits: same device
+functions, same RNG keys, same chunk order, same order of additions into a sample's radiance.
+
+(Regrouped by component in round 6; the tests themselves are unchanged.  Shared helpers: tests/gpu_common.py; the `dev` / `oracle` /
+`knobs` fixtures: tests/conftest.py.)"""
+import ctypes as C  # noqa: F401
+import json  # noqa: F401
+import os  # noqa: F401
+import subprocess  # noqa: F401
+import sys  # noqa: F401
+
+import numpy as np  # noqa: F401
 import pytest
 
-from tests.conftest import ROOT, scene_path
+from tests.conftest import ROOT, scene_path  # noqa: F401
+from tests import golden_cases as gc  # noqa: F401
+from tests.gpu_common import *  # noqa: F401,F403
+from tests.gpu_common import _bits, _counters, _directions, _edge_rays, _generated_assets, _lamp, _mesh_rays, _prim_array, _random_rays, _render_tiles, _ulp_neighbours, _within_bar  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
+
+@pytest.mark.parametrize("name,integ", [("cbox-spheres.toml", 1), ("cbox-spheres.toml", 0), ("brdf-row.toml", 1), ("two-spheres.toml", None)])
+def test_resident_and_streaming_pipelines_are_bit_identical(dev, oracle, name, integ):
+    """The single-launch resident pipeline (path state in LDS) and the multi-kernel streaming pipeline
+    (path state in HBM) run the same device functions with the same RNG keys and chunk order: same film,
+    same path statistics, and both within tolerance of the oracle."""
+    from lumillyrender_amd import abi
+    desc = load(name, 56, 40)
+    scene = dev.Scene(desc)
+    films, stats = [], []
+    for flags in (abi.LR_FLAG_RESIDENT, abi.LR_FLAG_STREAMING, abi.LR_FLAG_STREAMING | abi.LR_FLAG_COUNT):
+        p = desc.render_params(spp=24, seed=13, integrator=integ, flags=flags)
+        films.append(scene.render(p))
+        st = scene.stats()
+        stats.append((st.samples, st.segments, st.shadow_rays, st.kernel_launches[abi.LR_K_RESIDENT]))
+    assert stats[0][3] == 1 and stats[1][3] == 0            # the flags really selected the two pipelines
+    assert stats[0][:3] == stats[1][:3] == stats[2][:3]
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[1], films[2])
+    ref = oracle.render(desc, desc.render_params(spp=24, seed=13, integrator=integ))
+    assert linf(films[0], ref) < TOL
+    scene.close()
 
 
-@pytest.fixture(scope="module")
-def dev():
-    from lumillyrender_amd import device
-    assert device.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
-    return device
+def test_streaming_long_passes_lose_no_work(dev):
+    """With millions of path slots a k_trace workgroup pass spans many segments and k_shade shades whole ranges from
+    one work-item pool.  Every work item must still be rendered exactly once: the finished-sample counter equals
+    W*H*spp and the film is bit-identical to a 4096-slot render (an earlier version stranded items in pools of
+    list slices that ran empty near the end of the render: 10 % of the samples missing, nothing else wrong)."""
+    from lumillyrender_amd import abi
+    W, H, spp = 192, 128, 512                       # 24576 pixels x 64 chunks = 1.6 M work items
+    desc = load("mesh-box.toml", W, H)
+    scene = dev.Scene(desc)
+    films = []
+    for slots in (4096, 1 << 20, 0):
+        img = scene.render(desc.render_params(spp=spp, seed=9, flags=abi.LR_FLAG_STREAMING, path_slots=slots))
+        assert scene.stats().samples == W * H * spp, (slots, scene.stats().samples)
+        films.append(img)
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
+    desc2 = load("ibl-lens.toml", W, H)             # shadow lists ride on the same ranges
+    scene2 = dev.Scene(desc2)
+    a = scene2.render(desc2.render_params(spp=256, seed=2, flags=abi.LR_FLAG_STREAMING, path_slots=4096))
+    n_a = scene2.stats().samples
+    b = scene2.render(desc2.render_params(spp=256, seed=2, flags=abi.LR_FLAG_STREAMING, path_slots=0))
+    assert n_a == scene2.stats().samples == W * H * 256
+    assert np.array_equal(a, b)
+    scene.close(); scene2.close()
 
 
-@pytest.fixture(scope="module")
-def oracle():
-    from oracle import binding
-    return binding
+def test_sorted_and_unordered_variants_are_bit_identical(dev, knobs):
+    """LR_DENSE=0 (per-class lists + one k_shade launch per class instead of k_shade_all over the slots), LR_SORT=1 (rays
+    binned by octant / origin cell before trace and shadow), LR_SHADE_ORDER=0 (lists shaded in list order) and the number
+    of slot groups only change which lane handles which ray or vertex: same films, same counters."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    from lumillyrender_amd import abi
+    for name, spp in (("mesh-box.toml", 24), ("ibl-lens.toml", 16), ("brdf-row.toml", 16)):
+        desc = load(name, 160, 120)                     # 19200 pixels: several ranges, so the sort window is exercised with real lists
+        scene = dev.Scene(desc)
+        p = desc.render_params(spp=spp, seed=41, flags=abi.LR_FLAG_STREAMING)
+        base = scene.render(p)
+        st0 = scene.stats()
+        for env in ({"LR_DENSE": "0"}, {"LR_SORT": "1"}, {"LR_DENSE": "0", "LR_SORT": "1"}, {"LR_DENSE": "0", "LR_SHADE_ORDER": "0"},
+                    {"LR_DENSE": "0", "LR_SORT": "1", "LR_SHADE_ORDER": "0", "LR_MAXGROUP": "2"}, {"LR_GROUPS": "1"}, {"LR_GROUPS": "3"},
+                    {"LR_DENSE": "0", "LR_GROUPS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            img = scene.render(p)
+            st = scene.stats()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(img, base), (name, env)
+            assert (st.samples, st.segments, st.shadow_rays, st.sky_fetches) == (st0.samples, st0.segments, st0.shadow_rays, st0.sky_fetches), (name, env)
+        scene.close()
 
 
-def load(name, w, h, text_edit=None):
-    from lumillyrender_amd import host
-    if text_edit is None:
-        d = host.Description(scene_path(name))
-    else:
-        d = host.Description(text=text_edit(open(scene_path(name)).read()))
-    d.set_resolution(w, h)
-    return d
-
-
-def _generated_assets():
-    return os.path.exists(os.path.join(ROOT, "assets", "models", "blob", "blob.obj"))
-
-
-def _counters(st):
-    return (st.samples, st.segments, st.shadow_rays, st.sky_fetches)
-
-
-FLAT_CASES = [("cbox-spheres.toml", 1), ("cbox-spheres.toml", 0), ("brdf-row.toml", 1), ("brdf-row.toml", 0), ("two-spheres.toml", None)]
+def test_resident_workgroup_sizes_are_bit_identical(dev, oracle, knobs):
+    """The resident kernel runs 256- or 512-slot workgroups (the host picks 512 for flat scenes with several BSDF lists):
+    slots, chunking and RNG keys do not depend on it, so the films are the same bits -- and match the oracle."""
+    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
+    from lumillyrender_amd import abi
+    for name, integ in (("brdf-row.toml", 1), ("cbox-spheres.toml", 1), ("two-spheres.toml", None)):
+        desc = load(name, 72, 40)
+        scene = dev.Scene(desc)
+        films = []
+        for rb in ("256", "512"):
+            monkeypatch.setenv("LR_RES_BLOCK", rb)
+            films.append(scene.render(desc.render_params(spp=24, seed=17, integrator=integ, flags=abi.LR_FLAG_RESIDENT)))
+            assert scene.stats().pipeline == 1
+        monkeypatch.delenv("LR_RES_BLOCK")
+        assert np.array_equal(films[0], films[1]), name
+        ref = oracle.render(desc, desc.render_params(spp=24, seed=17, integrator=integ))
+        assert float(np.max(np.abs(films[1] - ref))) < TOL
+        scene.close()
 
 
 @pytest.mark.parametrize("name,integ", FLAT_CASES)
@@ -207,37 +274,6 @@ def test_fused_pipeline_on_random_tree_scenes(dev, oracle):
     assert done >= 10
 
 
-FULL_SIZE = [("brdf-row.toml", 960, 540), ("mesh-box.toml", 1920, 1370), ("ibl-lens.toml", 2048, 2048)]
-
-
-@pytest.mark.parametrize("name,W,H", FULL_SIZE)
-def test_full_size_properties_of_configs_3_to_5(dev, name, W, H):
-    """BASELINE configs 3-5 at their FULL film sizes (4 spp; the oracle is too slow there): the device's finished-sample
-    counter equals W*H*spp, every path statistic is positive, the film is finite (a GGX sample below the horizon has a
-    negative cosine and the reference, ggx.rs:87-113 / scene.rs:99, does not clamp it: slightly negative pixels are its
-    output too), and the frame rendered as four interleaved tile shards (what four GPUs would do) equals the untiled frame
-    bit for bit."""
-    if name != "brdf-row.toml" and not _generated_assets():
-        pytest.skip("generated assets missing (run __graft_entry__.build())")
-    from lumillyrender_amd import host
-    desc = load(name, W, H)
-    scene = dev.Scene(desc)
-    p = desc.render_params(spp=4, seed=21)
-    a = scene.render(p)
-    st = scene.stats()
-    assert st.samples == W * H * 4 and st.segments >= st.samples
-    assert np.isfinite(a).all() and a.max() > 0 and a.min() > -1e-2
-    out = np.zeros_like(a)
-    shard_samples = 0
-    for rank in range(4):
-        tiles, n = host.tiles(W, H, 64, rank, 4)
-        scene.render(p, tiles, n, out=out)
-        shard_samples += scene.stats().samples
-    assert shard_samples == W * H * 4
-    assert np.array_equal(a, out)
-    scene.close()
-
-
 @pytest.mark.parametrize("name,W,H", FULL_SIZE[1:])
 def test_full_size_film_is_pipeline_independent(dev, name, W, H):
     """Configs 4 and 5 at full film size (2 spp): the fused kernel (one launch, ~1800 workgroups that draw work items from
@@ -255,69 +291,6 @@ def test_full_size_film_is_pipeline_independent(dev, name, W, H):
     assert sa.pipeline == 2 and sb.pipeline == 0 and _counters(sa) == _counters(sb) and sa.samples == W * H * 2
     assert np.array_equal(a, b)
     scene.close()
-
-
-def test_bench_rccl_barrier_branch_runs(tmp_path):
-    """bench.py's N > 1 branch -- gloo default group, RCCL sub-group, all-reduce barrier around the timed region -- executed
-    on this box's one GPU (BENCH_FORCE_DIST=1, world 1), so that the driver's N-GPU run is not its first execution; the JSON
-    line says which barrier bracketed the timed region."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "192", "--height", "128",
-                        "--spp", "16", "--no-cpu-baseline", "--backend", "nccl", "--tile", "32"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["barrier"] == "RCCL all-reduce + device synchronize", (line["barrier"], r.stderr[-1500:])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and "other_configs" not in line
-
-
-@pytest.mark.parametrize("builder", ["ploc", "lbvh"])
-def test_device_builders_prune_only(dev, oracle, knobs, builder):
-    """the device builds the tree itself when the description carries none -- PLOC (default: bottom-up merging of
-    Morton-ordered clusters, subtrees collapsed into leaves by SAH cost; within 2 % of the host SAH tree's render rate, 3 ms for
-    10^5 triangles) or the round-1 Morton LBVH (LR_DEVICE_BVH=lbvh).  A tree only prunes: closest hits on random and grazing rays
-    equal the device's brute force over all primitives, the film equals the host-tree film bit for bit, for a mesh, a handful
-    of spheres, and the 2- and 3-primitive corner cases."""
-    monkeypatch = knobs                                  # (the knob build of the library: the product one reads no LR_* switch, csrc/lr_knobs.h)
-    if not _generated_assets():
-        pytest.skip("generated assets missing (run __graft_entry__.build())")
-    monkeypatch.setenv("LR_DEVICE_BVH", builder)
-    rng = np.random.default_rng(31)
-    desc = load("mesh-box.toml", 96, 64)
-    host_scene, dev_scene = dev.Scene(desc), dev.Scene(desc, device_bvh=True)
-    assert dev_scene.stats().bvh_build_ms > 0 and host_scene.stats().bvh_build_ms == 0
-    p = desc.render_params(spp=12, seed=4)
-    assert np.array_equal(host_scene.render(p), dev_scene.render(p))
-    n = 400_000
-    o = (rng.random((n, 3)) * 400 + 80).astype(np.float32)          # inside the box the mesh stands in
-    d = rng.standard_normal((n, 3)).astype(np.float32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
-    tp, tt = dev_scene.intersect(o, d)
-    bp, bt = dev_scene.intersect(o, d, brute=True)
-    assert np.array_equal(tp, bp) and np.array_equal(tt, bt)
-    assert (bp >= 0).mean() > 0.5
-    host_scene.close(); dev_scene.close()
-    for name in ("two-spheres.toml", "cbox-spheres.toml", "brdf-row.toml"):
-        dsc = load(name, 40, 30)
-        a, b = dev.Scene(dsc), dev.Scene(dsc, device_bvh=True)
-        q = dsc.render_params(spp=6, seed=9)                       # (flat scenes test every primitive; the tree is still built, collapsed and validated by lr_scene_create)
-        assert np.array_equal(a.render(q), b.render(q)), name
-        a.close(); b.close()
-
-
-def test_ploc_falls_back_on_needle_meshes(dev, monkeypatch, capfd):
-    """A mesh stretched 40:1 (tools/fuzz_traversal.py seed 515) makes PLOC's area-driven merging chain up to a height of ~100;
-    the builder then discards that tree for the radix tree, whose height the key length bounds, instead of refusing the scene.
-    Either way the tree only prunes: every ray gets brute force's primitive and distance bits."""
-    if not _generated_assets():
-        pytest.skip("generated assets missing (run __graft_entry__.build())")
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_traversal", os.path.join(ROOT, "tools", "fuzz_traversal.py"))
-    ft = importlib.util.module_from_spec(spec); spec.loader.exec_module(ft)
-    monkeypatch.setenv("LR_DEBUG", "1")
-    bad, excused, hit, n_prims, *_ = ft.run(515, 60_000)
-    err = capfd.readouterr().err
-    assert "falling back to the radix tree" in err, err[-600:]
-    assert bad == [0, 0] and excused == 0 and hit > 0.3
 
 
 @pytest.mark.gpu
@@ -340,3 +313,48 @@ def test_fused_kernels_get_the_workgroups_per_cu_they_are_sized_for(dev, monkeyp
         assert m, err[-400:]
         assert int(m.group(1)) >= int(m.group(2)) == want, (name, m.group(0))
         scene.close()
+
+
+def test_path_slots_bound_and_resident_request_that_does_not_fit(dev):
+    """LrRenderParams.path_slots is an upper bound for the fused pipeline (it used to be ignored), and LR_FLAG_RESIDENT on a scene
+    whose traversal stack does not fit the LDS beside the state now runs the default (fused) pipeline instead of dropping to the
+    streaming one.  Neither changes a film (RNG keys are scheduling-independent)."""
+    if not _generated_assets():
+        pytest.skip("generated assets missing")
+    from lumillyrender_amd import abi
+    desc = load("mesh-box.toml", 96, 64)
+    scene = dev.Scene(desc)
+    base = scene.render(desc.render_params(spp=8, seed=9)); st0 = scene.stats()
+    assert st0.pipeline == 2 and st0.path_slots > 4096
+    small = scene.render(desc.render_params(spp=8, seed=9, path_slots=3000)); st1 = scene.stats()
+    assert st1.pipeline == 2 and st1.path_slots == 3072                    # rounded up to whole 256-lane workgroups (and 512-slot segments)
+    assert np.array_equal(base.view(np.uint32), small.view(np.uint32))
+    res = scene.render(desc.render_params(spp=8, seed=9, flags=abi.LR_FLAG_RESIDENT)); st2 = scene.stats()
+    assert st2.pipeline in (1, 2)                                           # resident if it fits this scene's stack, else the default -- never streaming
+    assert np.array_equal(base.view(np.uint32), res.view(np.uint32))
+    scene.close()
+
+
+@pytest.mark.parametrize("case", STATED)
+def test_stated_spp_films_are_pipeline_independent(dev, case):
+    """At the stated spp the default pipeline, the streaming pipeline and (flat scenes) the resident and the fused one give the
+    same bits: same chunk schedule, same order of additions into a sample's radiance, same k_resolve."""
+    from lumillyrender_amd import abi
+    name, edit, _, _, spp, integ, seed, gen = case
+    if gen and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    desc = gc.load_scene(name, edit, 4, 4)
+    scene = dev.Scene(desc)
+    films, stats = {}, {}
+    flags = {"default": 0, "streaming": abi.LR_FLAG_STREAMING, "fused": abi.LR_FLAG_FUSED}
+    if name in ("cbox-spheres.toml", "brdf-row.toml"):
+        flags["resident"] = abi.LR_FLAG_RESIDENT
+    for k, f in flags.items():
+        films[k] = scene.render(desc.render_params(spp=spp, seed=seed, integrator=integ, flags=f))
+        s = scene.stats()
+        stats[k] = (s.samples, s.segments, s.shadow_rays, s.sky_fetches, s.pipeline)
+    assert stats["streaming"][4] == 0 and stats["fused"][4] == 2
+    for k in flags:
+        assert np.array_equal(_bits(films[k]), _bits(films["default"])), k
+        assert stats[k][:4] == stats["default"][:4], k
+    scene.close()
