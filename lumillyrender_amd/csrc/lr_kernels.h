@@ -489,10 +489,6 @@ LR_DEV TraceResult traverse(const DevScene& sc, V3 o, V3 d, float dist, uint32_t
 typedef float RowVec __attribute__((ext_vector_type(4)));
 typedef RowVec __attribute__((address_space(4))) ConstRow;
 LR_DEV float4 row4(RowVec v) { return make_float4(v.x, v.y, v.z, v.w); }
-// A 16-B row requested WHERE THIS IS WRITTEN.  LLVM sinks an ordinary load below a branch when every use lies behind it -- which turns
-// "all rows of a stage in one round trip, then a rarely taken branch, then the uses" into one exposed round trip per group of
-// uses.  A volatile load stays put (one global_load_dwordx4, the usual vmcnt bookkeeping).
-LR_DEV float4 row_now(const float4* p) { return row4(*(const volatile RowVec*)p); }
 
 // One primitive of the flat loop: triangle.rs:69-100 / sphere.rs:42-55 and the closest-hit fold.  Returns
 // true when the loop may stop (SHADOW: every lane of the wave already knows it is occluded).

@@ -753,13 +753,6 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, b
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
-#ifndef LR_CONN_ROWS_EARLY
-#define LR_CONN_ROWS_EARLY 0           // 1: the normal and emission rows of what the parked connection reached are requested with the own-box rows
-#endif
-// 1: the distance of what a parked connection reached is parked with it (1 KB of LDS more per workgroup); 0: re-derived where needed
-#ifndef LR_PARK_T
-#define LR_PARK_T 0
-#endif
 // the outcome of a connection's walk in one word: 0 = nothing in the window, w + 1 = primitive w hit inside it, -(x + 1) = occluded by x
 LR_DEV uint32_t conn_word(const PTrav& s) { return s.prim < 0 ? 0u : (s.occluded ? (uint32_t)-(s.prim + 1) : (uint32_t)(s.prim + 1)); }
 
@@ -785,7 +778,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   __shared__ uint32_t s_end[kBlock], s_spix[kBlock], s_sitem[kBlock], s_ssmp[kBlock];
   __shared__ uint32_t s_stat[ST_COUNT], s_pool[kPoolWords * kBlock / 64];
   __shared__ RowVec s_emit[NEE ? kEmitLds * 3 : 1];
-  __shared__ uint32_t s_conn[NEE ? (1 + LR_PARK_T) * kBlock : 1];    // the lane's parked connection (PathCtl::pend): conn_word [, the distance of what it reached]
+  __shared__ uint32_t s_conn[NEE ? kBlock : 1];                      // the lane's parked connection (PathCtl::pend): conn_word
   uint32_t* stk_n = lds;
   const uint32_t tid = threadIdx.x;
   float* s_lens = sc.cam.type == LR_CAMERA_THIN_LENS ? (float*)(lds + (size_t)sc.stack_lds * kBlock) : nullptr;
@@ -813,14 +806,14 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   while (true) {
     // ================= retire point (converged) =================
     // A lane with depth >= 0 has a ray; without `go` its walk is over.  (Few flags cross the walk: go, the spare count, has_sh, occluded.)
-    // (a) connections whose walk is over: the outcome is PARKED (two words in LDS) and the lane starts its continuation ray.  It is
+    // (a) connections whose walk is over: the outcome is PARKED (one word in LDS) and the lane starts its continuation ray.  It is
     // settled and resolved (scene.rs:127-147) at the lane's next vertex, where the wave's finished rays are densest: resolving the
     // one or two connections that end per burst on the spot ran ~70 instructions at 1-3 lanes, and the own-box test (bvh.rs:20-25)
     // would have doubled that.  The radiance still receives the connection before anything the next vertex adds: same sums.
     if constexpr (NEE) {
       const bool fs = __float_as_int(ls.ray_o.v.w) >= 0 && !go && c.has_sh;
       if (fs) {
-        s_conn[threadIdx.x] = conn_word(tr); if (LR_PARK_T) s_conn[kBlock + threadIdx.x] = __float_as_uint(tr.t);
+        s_conn[threadIdx.x] = conn_word(tr);
         c.has_sh = false; c.pend = true;
         ptrav_begin(tr, v3(ls.ray_d.v));
         go = true;
@@ -840,18 +833,12 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
       const float4 blo = sc.pbox[2 * pr], bhi = sc.pbox[2 * pr + 1];
       bool pm = false, cocc = false; int cp = -1; float ct = 0.0f;
       bool uc = false;
-#if LR_CONN_ROWS_EARLY
-      float4 csh = blo, cem = bhi;
-#endif
       if constexpr (NEE) {
         pm = fm && c.pend;
         LR_DIAG_ONLY(dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(pm));)
-        if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; if (LR_PARK_T) ct = __uint_as_float(s_conn[kBlock + threadIdx.x]); }
+        if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; }
         const size_t pc = cp >= 0 ? (size_t)cp : 0;
         const float4 clo = sc.pbox[2 * pc], chi = sc.pbox[2 * pc + 1];
-#if LR_CONN_ROWS_EARLY
-        csh = row_now(sc.shade + 4 * pc); cem = row_now(sc.shade + 4 * pc + 2);    // (with the box rows: one round trip)
-#endif
         uc = own_box_rejects(clo, chi, (pm && chk) ? cp : -1, o, v3(ls.sh_d.v));
       }
       const bool ur = own_box_rejects(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
@@ -860,24 +847,13 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
         const bool rm = pm && !uc;
         if (__ballot(rm) != 0) {
           if (rm) {
-#if !LR_PARK_T
             // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives it
             // again, the same bits (centre from the shading record, r^2 from the box rows)
             if (cp >= 0 && !cocc) {
-#if LR_CONN_ROWS_EARLY
-              const float4 sh = csh;
-#else
               const float4 sh = rec(cp, 0);
-#endif
               if (__float_as_uint(sh.w) >> 31) { const V3 co = o - v3(sh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, v3(ls.sh_d.v), &ct); }
             }
-#endif
-#if LR_CONN_ROWS_EARLY
-            auto crec = [&](int, int row) -> float4 { return row == 0 ? csh : cem; };
-            V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, crec);
-#else
             V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, rec);
-#endif
             ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
             c.pend = false;
           }
@@ -939,7 +915,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
         // continuation ray (see (a))
         const bool dc = live && !go && c.has_sh;
         if (dc) {
-          s_conn[threadIdx.x] = conn_word(tr); if (LR_PARK_T) s_conn[kBlock + threadIdx.x] = __float_as_uint(tr.t);
+          s_conn[threadIdx.x] = conn_word(tr);
           c.has_sh = false; c.pend = true;
           ptrav_begin(tr, v3(ls.ray_d.v));
           go = true;

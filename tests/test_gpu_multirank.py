@@ -89,6 +89,13 @@ def test_eight_rank_bench_assembles_the_single_rank_film(tmp_path, config, w, h)
     assert len(line["rank_upload_ms"]) == 8 and all(x > 0 for x in line["rank_upload_ms"])
     assert len(line["rank_host_bvh_build_s"]) == 8
     assert line["rank_render_ms"]["max"] >= line["rank_render_ms"]["min"] > 0
+    # every rank's share of the frame as per-rank lists (a SCALE run that falls short must say where)
+    ranks = line["ranks"]
+    for key in ("render_ms", "dominant_kernel", "dominant_kernel_ms", "render_call_ms", "readback_ms", "barrier_wait_ms", "host_bvh_build_s", "upload_ms", "pixels", "rays"):
+        assert len(ranks[key]) == 8, key
+    assert sum(ranks["pixels"]) == w * h and all(r > 0 for r in ranks["rays"]) and all(m > 0 for m in ranks["render_ms"])
+    assert all(c >= m for c, m in zip(ranks["render_call_ms"], ranks["render_ms"]))        # the call contains the device work
+    assert max(ranks["rays"]) <= 1.5 * (sum(ranks["rays"]) / 8)                              # the deal is even (32-px tiles of a small film)
     assert line["env_overrides"] == {k: v for k, v in env.items() if k.startswith("LR_")}
     assert set(glob.glob("/dev/shm/lumilly_film_*")) <= before
 

@@ -341,9 +341,11 @@ def test_own_box_definition_equals_the_literal_tree_walk(name, n):
     take the first primitive of the candidate order): an inner node's box never rejects what the leaf's box accepts.  And the
     box-free closest hit of rounds 1-5 (mode BRUTE) is NOT the same on such rays."""
     from tests import golden_cases as gc
-    if name == "mesh-box.toml" and not gc.have_generated_assets():
-        pytest.skip("generated assets missing")
+    if name == "mesh-box.toml" and (not gc.have_generated_assets() or os.environ.get("LUMILLY_TEST_LIGHT")):
+        pytest.skip("generated assets missing / the sanitizer run")
     d = host.Description(scene_path(name)); d.set_resolution(16, 16)
+    if os.environ.get("LUMILLY_TEST_LIGHT"):
+        n = max(2000, n // 20)                  # (the sanitizer run: tests/test_sanitizers.py)
     o, dr = _own_box_edge_rays(d, n, 31)
     p3, t3 = oracle.intersect(d, o, dr, mode=oracle.OWNBOX)
     p1, t1 = oracle.intersect(d, o, dr, mode=oracle.BVH, pad=0.0)
@@ -359,8 +361,8 @@ def test_own_box_definition_equals_the_literal_tree_walk(name, n):
     if name in ("cbox-spheres.toml", "brdf-row.toml"):
         p0, t0 = oracle.intersect(d, o, dr, mode=oracle.BRUTE)
         differ = (t0.view(np.uint32) != t3.view(np.uint32)) | ((p0 < 0) != (p3 < 0))
-        assert differ.sum() > 50, int(differ.sum())
-        if name == "cbox-spheres.toml":
+        assert differ.sum() > (50 if n >= 400_000 else 0), int(differ.sum())
+        if name == "cbox-spheres.toml" and n >= 400_000:
             assert (p7 != p3).sum() > 0        # the edge rays do produce exact ties between different primitives
 
 
@@ -369,7 +371,7 @@ def test_literal_render_is_audited_against_the_definition():
     or otherwise (flat scenes: the definition's loop over every primitive; the mesh: its tie rule on the walk's candidate list)."""
     from tests import golden_cases as gc
     cases = [("cbox-spheres.toml", 40, 40, 24, 1), ("brdf-row.toml", 48, 27, 16, 1)]
-    if gc.have_generated_assets():
+    if gc.have_generated_assets() and not os.environ.get("LUMILLY_TEST_LIGHT"):
         cases.append(("mesh-box.toml", 24, 18, 4, 0))
     for name, w, h, spp, integ in cases:
         d = host.Description(scene_path(name)); d.set_resolution(w, h)
@@ -387,7 +389,8 @@ def test_host_leaf_order_is_the_reference_candidate_order():
     oracle builds it), for every max_leaf -- also inside leaves of several primitives.  lr_scene_create numbers the primitives by it,
     which makes the kernels' "lowest id" tie rule bvh.rs:131-141's "first minimum of the candidate list"."""
     from tests import golden_cases as gc
-    names = ["cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"] + (["mesh-box.toml", "ibl-lens.toml"] if gc.have_generated_assets() else [])
+    big = gc.have_generated_assets() and not os.environ.get("LUMILLY_TEST_LIGHT")          # (the sanitizer run keeps the small scenes; the loader suite builds the big trees under ASan)
+    names = ["cbox-spheres.toml", "brdf-row.toml", "two-spheres.toml"] + (["mesh-box.toml", "ibl-lens.toml"] if big else [])
     for name in names:
         d = host.Description(scene_path(name))
         n = d.desc.n_prims
