@@ -14,13 +14,16 @@
 //   prims   3 x float4 per primitive (48 B) IN LEAF ORDER, so a leaf reads consecutive rows:
 //             triangle  {p0.xyz, id} {e1.xyz, -} {e2.xyz, -}     e1 = p1-p0, e2 = p2-p0 (triangle.rs:71-72)
 //             sphere    {c.xyz, id | 1<<31} {r, r*r, -, -} {-}
-//   shade   4 x float4 per primitive id (64 B, one cache line, the four loads of a vertex go out together):
-//             {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
-//             {color.rgb, type} {emission.rgb, weight} {param0..2, -}    = the primitive's material, denormalised
-//   pbox    2 x float4 per primitive id: the primitive's OWN exact box {min.xyz, -} {max.xyz, -} as triangle.rs:102-118 /
-//           sphere.rs:31-38 compute it.  bvh.rs:20-25 makes a primitive a candidate only if aabb.rs:74-92 passes on it:
-//           read once per query for the primitive that decides it (lr_kernels.h own_box_surely), and per primitive by the
-//           literal re-trace of the few undecided rays
+//   shade / pbox   ONE 128-B record per primitive id (kRecRows = 8 rows: one cache line, so the own-box rows the settle stage asks for
+//           bring the shading rows of the vertex that follows into L1 -- two arrays meant two lines and two full round trips per vertex):
+//             rows 0-3 (DevScene::shade points at row 0; the four loads of a vertex go out together):
+//               {n.xyz | c.xyz, material | sphere<<31}   (flat normal, triangle.rs:36)
+//               {color.rgb, type} {emission.rgb, weight} {param0..2, -}    = the primitive's material, denormalised
+//             rows 4-5 (DevScene::pbox points at row 4): the primitive's OWN exact box {min.xyz, r^2 of a sphere} {max.xyz, -} as
+//               triangle.rs:102-118 / sphere.rs:31-38 compute it.  bvh.rs:20-25 makes a primitive a candidate only if aabb.rs:74-92
+//               passes on it: read once per query for the primitive that decides it (lr_kernels.h own_box_surely), and per primitive
+//               by the literal re-trace of the few undecided rays
+//             rows 6-7 unused
 //   emit    3 x float4 per emitter (objects.rs:19-24, instance order):
 //             {p0|c .xyz, type} {p1.xyz | r, pdf} {p2.xyz, cumulative area}
 //   texels  float4 per IBL texel (rgb, -); or, when every texel of the map is a Radiance RGBE value (c * 2^(e - 136), the
@@ -47,6 +50,7 @@ constexpr int kStackLdsFused = 10;     // ... by k_path_tree, whose LDS also hol
 constexpr int kStackLdsMax = 16;       // traversal stack entries per lane kept in LDS by the streaming kernels; near-first order rarely goes deeper
                                        // (12 / 16 / 25 entries render the 100k-triangle configs at the same speed), the rest of the worst case spills
 constexpr int kNodeRows = 4;         // float4 rows per 4-wide node (64 B)
+constexpr int kRecRows = 8;          // float4 rows per primitive RECORD (128 B = one cache line): rows 0-3 shading, 4-5 the own box, 6-7 unused
 constexpr int kQMiss = 5;              // queue ids 0..4 = LR_MAT_*, 5 = miss
 constexpr int kNumShadeQueues = 6;
 constexpr int kFlatMax = 32;          // scenes up to this many primitives skip the tree
@@ -67,8 +71,8 @@ struct DevCamera {
 struct DevScene {
   const float4* nodes;
   const float4* prims;
-  const float4* shade;
-  const float4* pbox;                  // 2 rows per primitive id: its own exact box {min.xyz, r^2 of a sphere} {max.xyz, -} (bvh.rs:20-25 decides with it)
+  const float4* shade;                 // row 0 of the 128-B primitive records (kRecRows rows apart)
+  const float4* pbox;                  // row 4 of the same records: the primitive's own exact box {min.xyz, r^2 of a sphere} {max.xyz, -} (bvh.rs:20-25 decides with it)
   const float4* emit;
   const float4* texels;
   const uint32_t* texels_rgbe;         // non-null: the map as RGBE words r | g << 8 | b << 16 | e << 24 (e >= 10: every value normal or zero), texels unused

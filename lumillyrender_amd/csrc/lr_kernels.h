@@ -180,21 +180,16 @@ LR_DEV bool own_box_surely(float4 lo, float4 hi, V3 o, V3 d, float ix, float iy,
 #ifndef LR_NO_SETTLE
 #define LR_NO_SETTLE 0                 // measurement only (tools/build_variant.sh): skip the own-box stage = the closest hit over ALL primitives of rounds 1-5
 #endif
-// The winner `prim` of an unfiltered search is NOT a candidate (lo, hi = its own box rows; prim < 0: nothing to settle): the
-// approximate test first (every lane, ~40 instructions); where it cannot tell -- the hit lies within ~1e-6 relative of a face of
-// its own box as seen along the ray: 1e-3 of the hits on unit-sized triangles, 1e-5 on walls -- the literal test of THIS primitive
-// (3 IEEE divisions, under the lane mask); only a winner that really fails (~1e-6 of the rays) sends its query to the literal re-trace.
-LR_DEV bool own_box_rejects(float4 lo, float4 hi, int prim, V3 o, V3 d, float ix, float iy, float iz) {
+// The winner `prim` of an unfiltered search is NOT certainly a candidate (lo, hi = its own box rows; prim < 0: nothing to settle):
+// the approximate test, every lane, ~40 instructions, no branch.  Where it cannot tell -- the hit lies within ~1e-6 relative of a
+// face of its own box as seen along the ray: ~1e-3 of the hits on unit-sized triangles, ~1e-5 on walls -- the query is repeated
+// LITERALLY (every primitive test followed by own_box_exact); that costs one more walk for one ray in a thousand and keeps the
+// three IEEE divisions of the literal test out of the hot code.
+LR_DEV bool own_box_unsure(float4 lo, float4 hi, int prim, V3 o, V3 d) {
 #if LR_NO_SETTLE
   return false;
 #endif
-  const bool unsure = bool(prim >= 0) & !own_box_surely(lo, hi, o, d, ix, iy, iz);
-  bool rejected = false;
-  if (unsure) rejected = !own_box_exact(lo, hi, o, d);
-  return rejected;
-}
-LR_DEV bool own_box_rejects(float4 lo, float4 hi, int prim, V3 o, V3 d) {
-  return own_box_rejects(lo, hi, prim, o, d, __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  return bool(prim >= 0) & !own_box_surely(lo, hi, o, d, __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -326,10 +321,10 @@ LR_DEV bool trav_node(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
     const float az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * s.iz, bz = (g.z - s.o.z) * s.iz;
     // t(q) is monotonic in q with the sign of 1/d: the ray enters a slab through the lower plane when it travels up the
     // axis and through the upper plane otherwise -- pick the words once per node instead of a min and a max per plane pair
-    // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far -- none below a node that
-    // holds a sliver triangle (lr_scene_create sets qb.z): its Moeller-Trumbore distance may land in front of its own box
-    // (+ the culling slack of this node, lumilly_hip.hip Wide4Builder: a child is culled when it begins beyond
-    //  bound + kappa * diagonal + 2 kappa * t_far(child), the error bound of any Moeller-Trumbore distance inside it)
+    // box-pruning bound: the light's distance (+ the visibility window), or the closest hit so far, + the culling slack of this
+    // node (lumilly_hip.hip Wide4Builder: qb.z = 2 kappa, qb.w = kappa * diagonal): a child is culled when it begins beyond
+    // bound + kappa * diagonal + 2 kappa * t_far(child) -- the error bound of any Moeller-Trumbore distance inside it, which at
+    // grazing incidence may land in front of the triangle's own box
     const float bound = (SHADOW ? s.dist + 2.0f * kEps : s.t) + qb.w;
     const float slack2 = qb.z;
     const bool upx = s.ix >= 0.0f, upy = s.iy >= 0.0f, upz = s.iz >= 0.0f;
@@ -389,7 +384,7 @@ LR_DEV bool trav_leaf(const DevScene& sc, Trav<SHADOW>& s, const uint32_t* stk_n
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, s.o, s.d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), s.o, s.d, &t);
     if (!hit) continue;
-    if (LITERAL && !own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], s.o, s.d)) continue;
+    if (LITERAL && !own_box_exact(sc.pbox[kRecRows * (size_t)id], sc.pbox[kRecRows * (size_t)id + 1], s.o, s.d)) continue;
     if (SHADOW) {
       float diff = t - s.dist;
       if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return false; }   // (the occluder: own_box_settle_tree looks at its box)
@@ -416,8 +411,8 @@ LR_DEV void retrace_tree(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
 template <bool SHADOW>
 LR_DEV void own_box_settle_tree(const DevScene& sc, Trav<SHADOW>& s, uint32_t* stk_n) {
   const size_t pi = s.prim < 0 ? 0 : (size_t)s.prim;
-  const float4 lo = sc.pbox[2 * pi], hi = sc.pbox[2 * pi + 1];
-  if (own_box_rejects(lo, hi, s.prim, s.o, s.d)) retrace_tree<SHADOW>(sc, s, stk_n);
+  const float4 lo = sc.pbox[kRecRows * pi], hi = sc.pbox[kRecRows * pi + 1];
+  if (own_box_unsure(lo, hi, s.prim, s.o, s.d)) retrace_tree<SHADOW>(sc, s, stk_n);
 }
 
 // A burst of traversal for the lanes with `go` set (while-while: the wave first descends inner nodes
@@ -550,15 +545,15 @@ LR_DEV void retrace_flat(const float4* __restrict__ prims, const float4* __restr
     float t = 0.0f; bool hit;
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
-    if (hit && t < bt && own_box_exact(row4(boxes[2 * id]), row4(boxes[2 * id + 1]), o, d)) { bt = t; bp = id; }
+    if (hit && t < bt && own_box_exact(row4(boxes[kRecRows * id]), row4(boxes[kRecRows * id + 1]), o, d)) { bt = t; bp = id; }
   }
   t_out = bt; prim_out = bp;
 }
 // settle the winner of the unfiltered search (t, prim) of a flat scene: certainly a candidate, or the literal query
 LR_DEV void own_box_settle_flat(const float4* __restrict__ prims, const float4* __restrict__ pbox, int n, V3 o, V3 d, float& t, int& prim) {
   const int pi = prim < 0 ? 0 : prim;
-  const float4 lo = pbox[2 * pi], hi = pbox[2 * pi + 1];
-  if (own_box_rejects(lo, hi, prim, o, d)) retrace_flat(prims, pbox, n, o, d, t, prim);
+  const float4 lo = pbox[kRecRows * pi], hi = pbox[kRecRows * pi + 1];
+  if (own_box_unsure(lo, hi, prim, o, d)) retrace_flat(prims, pbox, n, o, d, t, prim);
 }
 // scene.rs:127-131 on the settled closest hit of a connection: nearer than the window = occluded, beyond it = no hit
 LR_DEV void shadow_window(float dist, float t, int& prim, bool& occluded) {
@@ -1561,7 +1556,7 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
   if (MT != kQMiss) {
     // resident pipeline: the hit record lives in the slot's (not yet written) shadow-weight row
     if (st.hit) in.h = st.hit[slot]; else { float4 w = st.sh_w[slot]; in.h = make_float2(w.x, w.y); }
-    const float4* rec = sc.shade + 4 * (size_t)__float_as_int(in.h.y);   // one 64-B record: no dependent second fetch for the material
+    const float4* rec = sc.shade + kRecRows * (size_t)__float_as_int(in.h.y);   // one 64-B record: no dependent second fetch for the material
     in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
   }
   return shade_vertex_core<MT>(sc, st, rp, slot, in);
@@ -1571,7 +1566,7 @@ LR_DEV VertexOut shade_vertex(const DevScene& sc, const DevState& st, const DevP
 LR_DEV void shadow_resolve(const DevScene& sc, const DevState& st, uint32_t slot, V3 o, V3 dir, const TraceResult& r) {
   if (!r.occluded && r.prim >= 0) {                                // scene.rs:127-131
     V3 pos = o + dir * r.t;
-    const float4* rec = sc.shade + 4 * (size_t)r.prim;
+    const float4* rec = sc.shade + kRecRows * (size_t)r.prim;
     float4 sh = rec[0], em = rec[2];
     uint32_t mw = __float_as_uint(sh.w);
     V3 light_normal = (mw >> 31) ? normalize(pos - v3(sh)) : v3(sh);
@@ -1709,7 +1704,7 @@ __global__ void __launch_bounds__(kBlock, LR_DENSE_WAVES) k_shade_all(DevScene s
         int prim = __float_as_int(in.h.y);
         key = kQMiss;
         if (prim >= 0) {
-          const float4* rec = sc.shade + 4 * (size_t)prim;
+          const float4* rec = sc.shade + kRecRows * (size_t)prim;
           in.sh = rec[0]; in.m0 = rec[1]; in.m1 = rec[2]; in.m2 = rec[3];
           key = (int)__float_as_uint(in.m0.w);                      // {color.rgb, type bits}: the record names its own class
         } else if (ibl) {
@@ -2231,7 +2226,7 @@ __global__ void __launch_bounds__(kBlock) k_selftest_brute(const float4* __restr
     float t = 0.0f; bool hit;
     if (idw >> 31) hit = sphere_test(v3(q0), q1.y, o, d, &t);
     else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
-    if (hit && pbox) hit = own_box_exact(row4(((const ConstRow*)pbox)[2 * (size_t)id]), row4(((const ConstRow*)pbox)[2 * (size_t)id + 1]), o, d);
+    if (hit && pbox) hit = own_box_exact(row4(((const ConstRow*)pbox)[kRecRows * (size_t)id]), row4(((const ConstRow*)pbox)[kRecRows * (size_t)id + 1]), o, d);
     if (hit && (t < best || (t == best && id < bp))) { best = t; bp = id; }
   }
   if (valid) { prim_out[i] = bp; t_out[i] = bp >= 0 ? best : 0.0f; }

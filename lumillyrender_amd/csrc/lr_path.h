@@ -434,11 +434,11 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
   if (tid < ST_COUNT) s_stat[tid] = 0;
   if (tid < kPoolWords * kBlock / 64) s_pool[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 4u; i += kBlock) {
-    float4 v = sc.shade[i];
+    float4 v = sc.shade[(i >> 2) * kRecRows + (i & 3u)];
     s_rec[(i >> 2) * kRecStride + (i & 3u)] = (RowVec){v.x, v.y, v.z, v.w};
   }
   for (uint32_t i = tid; i < (uint32_t)sc.n_flat * 2u; i += kBlock) {      // rows 4, 5: the primitive's own box (bvh.rs:20-25)
-    float4 v = sc.pbox[i];
+    float4 v = sc.pbox[(i >> 1) * kRecRows + (i & 1u)];
     s_rec[(i >> 1) * kRecStride + 4u + (i & 1u)] = (RowVec){v.x, v.y, v.z, v.w};
   }
   for (uint32_t i = tid; i < (uint32_t)sc.n_emitters * 3u && i < (uint32_t)kFlatMax * 3u; i += kBlock) {
@@ -488,9 +488,9 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
         // bvh.rs:20-25: the own box of each winner has the last word (lr_kernels.h own_box_surely); box rows from LDS
         {
           const int pa = h.prim < 0 ? 0 : h.prim, pb = h.sprim < 0 ? 0 : h.sprim;
-          const bool ua = own_box_rejects(rec(pa, 4), rec(pa, 5), h.prim, o, d);
-          const bool ub = own_box_rejects(rec(pb, 4), rec(pb, 5), h.sprim, o, sd);
-          if (ua | ub) {                                             // cold: ~1e-6 of the rays
+          const bool ua = own_box_unsure(rec(pa, 4), rec(pa, 5), h.prim, o, d);
+          const bool ub = own_box_unsure(rec(pb, 4), rec(pb, 5), h.sprim, o, sd);
+          if (ua | ub) {                                             // cold: ~1e-5 of the rays
 #pragma unroll 1
             for (int w = 0; w < 2; ++w) {
               if (w ? ub : ua) {
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(kBlock, LR_PATH_WAVES) k_path_flat(DevScene sc
       } else {
         TraceResult r = traverse_flat_raw<false>(flat_prims, sc.n_flat, o, d, 0.0f);
         const int pa = r.prim < 0 ? 0 : r.prim;
-        if (own_box_rejects(rec(pa, 4), rec(pa, 5), r.prim, o, d)) retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, d, r.t, r.prim);
+        if (own_box_unsure(rec(pa, 4), rec(pa, 5), r.prim, o, d)) retrace_flat(flat_prims, sc.pbox, sc.n_flat, o, d, r.t, r.prim);
         t = r.t; prim = r.prim;
       }
     }
@@ -656,8 +656,9 @@ LR_DEV bool tri_test_bf(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {
   return bool(!(__builtin_fabsf(det) < kEps)) & bool(!(u < 0.0f)) & bool(!(u > 1.0f)) & bool(!(v < 0.0f)) & bool(!(u + v > 1.0f)) & bool(!(t < kEps));
 }
 // one primitive of a leaf against the lane's ray; true = a connection found its occluder (the walk is over)
-// lit (PathCtl::lit, almost never set: a wave-level skip): a primitive whose own test accepts counts only if aabb.rs:74-92 passes on
-// its own box (bvh.rs:20-25)
+// lit (PathCtl::lit, almost never set: a lane-mask skip per primitive.  Choosing between two instantiations of the leaf once per
+// leaf step with a wave-uniform flag measured 1-1.4 % SLOWER on configs 4 / 5: the second copy of the leaf cost registers): a
+// primitive whose own test accepts counts only if aabb.rs:74-92 passes on its own box (bvh.rs:20-25)
 template <bool CONN, class LS>
 LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bool lit, V3 o, V3 d, float4 q0, float4 q1, float4 q2) {
   uint32_t idw = __float_as_uint(q0.w);
@@ -671,7 +672,7 @@ LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bo
   else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
 #endif
   if (!hit) return false;
-  if (lit) { if (!own_box_exact(sc.pbox[2 * (size_t)id], sc.pbox[2 * (size_t)id + 1], o, d)) return false; }
+  if (lit) { if (!own_box_exact(sc.pbox[kRecRows * (size_t)id], sc.pbox[kRecRows * (size_t)id + 1], o, d)) return false; }
   if (CONN && conn) {
     float diff = t - ls.sh_d.v.w;
     if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return true; }   // (the occluder: ptrav_settle looks at its own box)
@@ -753,6 +754,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, b
   LR_DIAG_ONLY(if (lm) { dg->leaf_steps += 1; dg->leaf_lanes += (unsigned)__builtin_popcountll(lm); dg->cyc_leaf += __builtin_amdgcn_s_memtime() - t1; })
 }
 
+#ifndef LR_FAKE_SETTLE
+#define LR_FAKE_SETTLE 0
+#endif
 // the outcome of a connection's walk in one word: 0 = nothing in the window, w + 1 = primitive w hit inside it, -(x + 1) = occluded by x
 LR_DEV uint32_t conn_word(const PTrav& s) { return s.prim < 0 ? 0u : (s.occluded ? (uint32_t)-(s.prim + 1) : (uint32_t)(s.prim + 1)); }
 
@@ -791,7 +795,7 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
   const bool emit_lds = NEE && sc.n_emitters <= kEmitLds;
   if (emit_lds && tid < (uint32_t)sc.n_emitters * 3u) { float4 v = sc.emit[tid]; s_emit[tid] = (RowVec){v.x, v.y, v.z, v.w}; }
   __syncthreads();
-  auto rec = [&](int prim, int row) -> float4 { return sc.shade[4 * (size_t)prim + row]; };
+  auto rec = [&](int prim, int row) -> float4 { return sc.shade[kRecRows * (size_t)prim + row]; };
 
   LaneStateT<false> ls;
   ls.emit = emit_lds ? (const LdsRow*)s_emit : nullptr;
@@ -824,13 +828,19 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
     const bool fm = __float_as_int(ls.ray_o.v.w) >= 0 && !go;         // (a) left only closest-hit walks among these
     if (__ballot(fm) != 0) {
       LR_DIAG_ONLY(tq = __builtin_amdgcn_s_memtime(); if (!NEE) { dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(fm && tr.prim >= 0)); })
-      // ---- settle (lr_kernels.h own_box_rejects): is each winner a candidate under bvh.rs:20-25?  One round trip for the own-box
-      // rows of both.  A lane in literal mode has been through this: its walks tested every primitive's own box themselves ----
+      // ---- settle (lr_kernels.h own_box_unsure): is each winner certainly a candidate under bvh.rs:20-25?  Straight-line code.  (The
+      // shading rows of the vertex are NOT requested up here with the own-box rows: measured 2.3 % slower on configs 4 and 5 --
+      // 16 more registers live across the settle arithmetic cost more than the second round trip.)  A lane in literal mode has been
+      // through this: its walks tested every primitive's own box themselves ----
       const V3 o = v3(ls.ray_o.v);
       const bool chk = fm && !c.lit;
       const bool hitv = chk && tr.prim >= 0;
-      const size_t pr = hitv ? (size_t)tr.prim : 0;
-      const float4 blo = sc.pbox[2 * pr], bhi = sc.pbox[2 * pr + 1];
+      const size_t pr = (fm && tr.prim >= 0) ? (size_t)tr.prim : 0;
+#if LR_FAKE_SETTLE      // measurement only (wrong results): the settle arithmetic on rows the vertex requests anyway -- what the own-box rows' round trip costs
+      const float4 blo = sc.shade[kRecRows * pr + 1], bhi = sc.shade[kRecRows * pr + 2];
+#else
+      const float4 blo = sc.pbox[kRecRows * pr], bhi = sc.pbox[kRecRows * pr + 1];
+#endif
       bool pm = false, cocc = false; int cp = -1; float ct = 0.0f;
       bool uc = false;
       if constexpr (NEE) {
@@ -838,39 +848,40 @@ __global__ void __launch_bounds__(kBlock, path_tree_waves_c(NEE)) k_path_tree(De
         LR_DIAG_ONLY(dg.n_resolve += 1; dg.l_resolve += (unsigned)__builtin_popcountll(__ballot(pm));)
         if (pm) { const int w = (int)s_conn[threadIdx.x]; cocc = w < 0; cp = (w < 0 ? -w : w) - 1; }
         const size_t pc = cp >= 0 ? (size_t)cp : 0;
-        const float4 clo = sc.pbox[2 * pc], chi = sc.pbox[2 * pc + 1];
-        uc = own_box_rejects(clo, chi, (pm && chk) ? cp : -1, o, v3(ls.sh_d.v));
-      }
-      const bool ur = own_box_rejects(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
-      // ---- the parked connection's radiance (scene.rs:127-147), unless its own box just rejected it ----
-      if constexpr (NEE) {
+        const float4 clo = sc.pbox[kRecRows * pc], chi = sc.pbox[kRecRows * pc + 1];
+        const float4 csh = sc.shade[kRecRows * pc], cem = sc.shade[kRecRows * pc + 2];
+        uc = own_box_unsure(clo, chi, (pm && chk) ? cp : -1, o, v3(ls.sh_d.v));
+        // ---- the parked connection's radiance (scene.rs:127-147), unless its own box is in doubt ----
         const bool rm = pm && !uc;
-        if (__ballot(rm) != 0) {
-          if (rm) {
-            // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives it
-            // again, the same bits (centre from the shading record, r^2 from the box rows)
-            if (cp >= 0 && !cocc) {
-              const float4 sh = rec(cp, 0);
-              if (__float_as_uint(sh.w) >> 31) { const V3 co = o - v3(sh); (void)sphere_test_co(co, sqr_norm(co), sc.pbox[2 * (size_t)cp].w, v3(ls.sh_d.v), &ct); }
-            }
-            V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, rec);
-            ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
-            c.pend = false;
-          }
+        if (rm) {
+          // the distance is not parked: only a sphere's normal needs it (scene.rs:135, sphere.rs:57-62), and the sphere's own test gives it
+          // again, the same bits (centre from the shading record, r^2 from the box rows)
+          if (cp >= 0 && !cocc && (__float_as_uint(csh.w) >> 31)) { const V3 co = o - v3(csh); (void)sphere_test_co(co, sqr_norm(co), clo.w, v3(ls.sh_d.v), &ct); }
+          auto crec = [&](int, int row) -> float4 { return row == 0 ? csh : cem; };
+          V3 L = path_shadow_resolve(v3(ls.rad.v), o, v3(ls.sh_d.v), v3(ls.sh_w.v), cocc, cp, ct, crec);
+          ls.rad.v = make_float4(L.x, L.y, L.z, ls.rad.v.w);
+          c.pend = false;
         }
       }
-      // ---- a rejected winner (~1e-6 of the rays): the lane walks again among the others, LITERALLY (ptrav_prim tests every
-      // primitive's own box).  A rejected connection is walked first, the continuation ray after it as always ----
+#if LR_FAKE_SETTLE
+      bool ur = own_box_unsure(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
+      { int keep = ur ? 1 : 0; asm volatile("" :: "v"(keep)); ur = false; }
+#else
+      const bool ur = own_box_unsure(blo, bhi, hitv ? tr.prim : -1, o, v3(ls.ray_d.v));
+#endif
+      // ---- a winner in doubt (~1e-3 of the hits on unit-sized triangles, ~1e-5 on walls): the lane walks again among the others,
+      // LITERALLY (ptrav_prim tests every primitive's own box).  A connection in doubt is walked first, the continuation ray after
+      // it as always.  (Handled behind the vertex of the other lanes: no branch between the row requests and their use.) ----
       const bool redo = ur | uc;
+      const bool vm = fm && !redo;                                   // the lanes whose vertex runs now
+      LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(vm));)
+      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, vm, tr.t, tr.prim, rec, s_stat);
+      c.lit = c.lit && !vm;
       if (redo) {
         if (NEE && uc) { c.has_sh = true; c.pend = false; ptrav_begin(tr, v3(ls.sh_d.v)); }
         else ptrav_begin(tr, v3(ls.ray_d.v));
         c.lit = true; go = true;
       }
-      const bool vm = fm && !redo;                                   // the lanes whose vertex runs now
-      LR_DIAG_ONLY(dg.cyc_resolve += __builtin_amdgcn_s_memtime() - tq; tq = __builtin_amdgcn_s_memtime(); dg.n_vertex += 1; dg.l_vertex += (unsigned)__builtin_popcountll(__ballot(vm));)
-      path_vertex<MTS, NEE ? 1 : 0>(sc, rp, ls, c, vm, tr.t, tr.prim, rec, s_stat);
-      c.lit = c.lit && !vm;
       LR_DIAG_ONLY(dg.cyc_vertex += __builtin_amdgcn_s_memtime() - tq;)
     }
     // (c) paths that ended (or lanes without a work item yet): fold, next item, next camera sample

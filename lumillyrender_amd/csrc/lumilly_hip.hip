@@ -97,7 +97,7 @@ struct LrScene {
   hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] setup done, [1], [2] group 1 / 2 batch done
   int n_cus = 0;
   // scene blob
-  DevBuf<float4> nodes, prims, flat, shade, pbox, emit, texels;
+  DevBuf<float4> nodes, prims, flat, shade, emit, texels;
   DevBuf<uint32_t> texels_rgbe;        // the IBL map as RGBE words when every texel re-encodes exactly (lr_device.h)
   DevBuf<uint8_t> prim_qid;
   DevScene dev;
@@ -291,8 +291,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
   }
 
   // per-primitive shading rows + emitter table (objects.rs:19-24) in instance order
-  std::vector<float4> shade((size_t)np * 4), emit;
-  std::vector<float4> pbox((size_t)std::max(np, 1) * 2, make_float4(0, 0, 0, 0));   // the primitive's own exact box (lr_device.h): bvh.rs:20-25 decides with it
+  std::vector<float4> shade((size_t)std::max(np, 1) * kRecRows, make_float4(0, 0, 0, 0)), emit;      // the 128-B primitive records (lr_device.h): rows 0-3 shading, 4-5 own box
   std::vector<uint8_t> qid((size_t)np);
   std::vector<float> area((size_t)np);
   std::vector<uint8_t> sliver((size_t)np, 0);
@@ -311,11 +310,11 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
       double l2 = std::sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]);
       if (!(l1 * l2 < 1.329227995784916e36)) fail(LR_EUNSUPPORTED, "triangle " + std::to_string(i) + ": |e1| |e2| >= 2^120 is outside the exact-arithmetic range of the device path");
       float nrm = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-      shade[4 * i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
+      shade[kRecRows * (size_t)i] = make_float4(c[0] / nrm, c[1] / nrm, c[2] / nrm, __builtin_bit_cast(float, mw));
       area[i] = nrm * 0.5f;
-      pbox[2 * (size_t)i] = make_float4(std::fmin(std::fmin(p.v[0], p.v[3]), p.v[6]), std::fmin(std::fmin(p.v[1], p.v[4]), p.v[7]),      // triangle.rs:102-118
+      shade[kRecRows * (size_t)i + 4] = make_float4(std::fmin(std::fmin(p.v[0], p.v[3]), p.v[6]), std::fmin(std::fmin(p.v[1], p.v[4]), p.v[7]),      // triangle.rs:102-118
                                         std::fmin(std::fmin(p.v[2], p.v[5]), p.v[8]), 0.0f);
-      pbox[2 * (size_t)i + 1] = make_float4(std::fmax(std::fmax(p.v[0], p.v[3]), p.v[6]), std::fmax(std::fmax(p.v[1], p.v[4]), p.v[7]),
+      shade[kRecRows * (size_t)i + 5] = make_float4(std::fmax(std::fmax(p.v[0], p.v[3]), p.v[6]), std::fmax(std::fmax(p.v[1], p.v[4]), p.v[7]),
                                             std::fmax(std::fmax(p.v[2], p.v[5]), p.v[8]), 0.0f);
       // triangle.rs:69-100 divides by det = e1 . (d x e2) = |e1||e2| sin(phi) cos(theta): with a small angle phi between the edges
       // at p0 the distance t = (e2 . qv) / det carries a relative error of ~eps / (sin(phi) cos(theta)) for EVERY direction, enough
@@ -327,12 +326,12 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
         tri_a[i] = (float)(l1 * l2 * (1.0 + 1e-6));
       }
     } else if (p.type == LR_PRIM_SPHERE) {                       // sphere.rs:21-29
-      shade[4 * i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
+      shade[kRecRows * (size_t)i] = make_float4(p.v[0], p.v[1], p.v[2], __builtin_bit_cast(float, mw | 0x80000000u));
       area[i] = 4.0f * kPi * (p.v[3] * p.v[3]);
-      pbox[2 * (size_t)i] = make_float4(p.v[0] - p.v[3], p.v[1] - p.v[3], p.v[2] - p.v[3], p.v[3] * p.v[3]);   // sphere.rs:31-38; .w = r^2 (k_path_tree re-derives a parked hit's distance)
-      pbox[2 * (size_t)i + 1] = make_float4(p.v[0] + p.v[3], p.v[1] + p.v[3], p.v[2] + p.v[3], 0.0f);
+      shade[kRecRows * (size_t)i + 4] = make_float4(p.v[0] - p.v[3], p.v[1] - p.v[3], p.v[2] - p.v[3], p.v[3] * p.v[3]);   // sphere.rs:31-38; .w = r^2 (k_path_tree re-derives a parked hit's distance)
+      shade[kRecRows * (size_t)i + 5] = make_float4(p.v[0] + p.v[3], p.v[1] + p.v[3], p.v[2] + p.v[3], 0.0f);
     } else fail(LR_EINVAL, "unknown primitive type");
-    for (int k = 0; k < 3; ++k) shade[4 * i + 1 + k] = mats[3 * (size_t)p.material + k];
+    for (int k = 0; k < 3; ++k) shade[kRecRows * (size_t)i + 1 + k] = mats[3 * (size_t)p.material + k];
     int mt = d.materials[p.material].type;
     qid[i] = (uint8_t)mt;
     s.mat_present[mt] = true;
@@ -539,7 +538,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
     }
     s.flat.upload(flat, s.stream);
   }
-  s.shade.upload(shade, s.stream); s.pbox.upload(pbox, s.stream);
+  s.shade.upload(shade, s.stream);
   s.emit.upload(emit, s.stream); s.texels.upload(texels, s.stream);
   if (!texels_rgbe.empty()) s.texels_rgbe.upload(texels_rgbe, s.stream);
   s.prim_qid.upload(qid, s.stream);
@@ -547,7 +546,7 @@ void pack_scene(LrScene& s, const LrSceneDesc& d) {
 
   DevScene& v = s.dev;
   std::memset(&v, 0, sizeof(v));
-  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.pbox = s.pbox.p; v.emit = s.emit.p;
+  v.nodes = s.nodes.p; v.prims = s.prims.p; v.shade = s.shade.p; v.pbox = s.shade.p + 4; v.emit = s.emit.p;
   v.texels = s.texels.p; v.prim_qid = s.prim_qid.p;
   v.texels_rgbe = texels_rgbe.empty() ? nullptr : s.texels_rgbe.p;
   v.n_flat = (np > 0 && np <= kFlatMax) ? np : 0;
@@ -1395,7 +1394,7 @@ static int selftest_brute(LrScene* s, bool own_box, int n, const float* origins,
     dor.ensure((size_t)n * 3); ddr.ensure((size_t)n * 3); dt.ensure(n); dpr.ensure(n);
     HIP_OK(hipMemcpy(dor.p, origins, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(ddr.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
-    if (n > 0) hipLaunchKernelGGL(k_selftest_brute, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, (const float4*)s->prims.p, own_box ? (const float4*)s->pbox.p : (const float4*)nullptr, s->n_prims, dor.p, ddr.p, dpr.p, dt.p, n);
+    if (n > 0) hipLaunchKernelGGL(k_selftest_brute, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, (const float4*)s->prims.p, own_box ? (const float4*)s->dev.pbox : (const float4*)nullptr, s->n_prims, dor.p, ddr.p, dpr.p, dt.p, n);
     HIP_OK(hipGetLastError()); HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(prim_out, dpr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) if (prim_out[i] >= 0 && (size_t)prim_out[i] < s->user_id.size()) prim_out[i] = s->user_id[(size_t)prim_out[i]];   // device id -> the caller's index
