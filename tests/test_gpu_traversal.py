@@ -394,3 +394,33 @@ def test_tree_scenes_follow_the_own_box_definition_on_edge_rays(dev, oracle):
     assert np.array_equal(lp[:m], op) and np.array_equal(lt[:m], ot)
     assert np.array_equal(lt, bt) and (lp != bp).mean() < 0.05              # same distances; other primitives at exact ties only
     scene.close(); lb.close()
+
+
+def test_hits_beyond_1e5_are_dropped_like_the_reference(dev, oracle):
+    """aabb.rs:74-92 seeds its slab interval with [-INF, INF], INF = 1e5 (constant.rs:3): a primitive whose own box begins beyond 1e5
+    units along the ray is never a candidate, whatever its own test says (SURVEY section 7 lists the clip among the quirks that must
+    survive).  A radius-100 sphere seen from 150 000 units away: the reference sees the sky; the box-free closest hit sees the sphere.
+    From 90 000 units the same sphere is there on both sides."""
+    def far_camera(dist):
+        def edit(t):
+            t = t.replace("origin = [0, 0, 10]", f"origin = [0, 0, {dist}]").replace("radius = 1 }", "radius = 100 }").replace("fov = 53.13", "fov = 0.05")
+            i = t.index('[[object]]\nmesh = "planet"')                    # (the scene without its ground sphere)
+            return t[:i]
+        return edit
+    for dist, visible in ((150000, False), (90000, True)):
+        desc = load("two-spheres.toml", 24, 24, text_edit=far_camera(dist))
+        scene = dev.Scene(desc)
+        p = desc.render_params(spp=8, seed=2)
+        img = scene.render(p)
+        ref, so = oracle.render(desc, p, mode=oracle.BVH, pad=0.0, with_stats=True)
+        st = scene.stats()
+        assert (st.samples, st.segments) == (so.samples, so.segments)
+        assert float(np.max(np.abs(img - ref))) < TOL
+        centre = img[10:14, 10:14]
+        assert bool(np.all(centre == 1.0)) == (not visible)               # the white sky, or the grey sphere
+        cam = np.array(desc.desc.camera.aperture_position[:3], dtype=np.float32)
+        o = np.tile(cam, (16, 1)); d = np.tile(np.array([0, 0, -1], dtype=np.float32), (16, 1))
+        tp, tt = scene.intersect(o, d)
+        ap, at = scene.intersect(o, d, brute="all")
+        assert np.all(ap == 0) and np.all((tp == 0) == visible)
+        scene.close()
