@@ -127,10 +127,13 @@ LR_DEV bool sphere_test(V3 c, float r2, V3 o, V3 d, float* t_out) {
 //   own_box_surely   one approximate slab test with a margin on every comparison: true = the literal test certainly
 //                    passes, so the winner of the unfiltered search is the winner of the filtered one (every other
 //                    candidate is no nearer);
-//   otherwise        (~1e-5 of the rays: the hit lies within ~1e-6 relative of a face of its own box, or a direction
-//                    component is ~0) the query is repeated LITERALLY: every primitive test followed by own_box_exact,
-//                    the reference's operations in the reference's order (retrace_flat / retrace_tree; cold code).
-// pbox: two rows per primitive id, {min.xyz, -} {max.xyz, -} as triangle.rs:102-118 / sphere.rs:31-38 compute them.
+//   otherwise        (~1e-3 of the hits on unit-sized triangles, ~1e-5 on walls: the hit lies within ~1e-6 relative of a
+//                    face of its own box as seen along the ray, or a direction component is ~0) the query is repeated
+//                    LITERALLY: every primitive test followed by own_box_exact, the reference's operations in the
+//                    reference's order (retrace_flat / retrace_tree: cold code; k_path_tree: the lane walks again among
+//                    the others in literal mode, lr_path.h PathCtl::lit).
+// pbox: rows 4 and 5 of the primitive's 128-B record (lr_device.h), {min.xyz, r^2 of a sphere} {max.xyz, -} as
+// triangle.rs:102-118 / sphere.rs:31-38 compute them.
 // ------------------------------------------------------------------------------------------
 LR_DEV bool own_box_exact(float4 lo, float4 hi, V3 o, V3 d) {                   // aabb.rs:74-92, line by line
   float mn = -kInf, mx = kInf;
@@ -198,7 +201,7 @@ LR_DEV bool own_box_unsure(float4 lo, float4 hi, int prim, V3 o, V3 d) {
 // test may use fused / approximate arithmetic: it only prunes, never decides.
 //   SHADOW: accept only hits with t - dist <= EPS; stop at the first hit with t - dist < -EPS
 //   (then the closest hit is at least that near and scene.rs:129 rejects the connection); the occluder's id and
-//   distance are kept, because its own box has the last word (own_box_settle).
+//   distance are kept, because its own box has the last word (own_box_settle_tree / the vertex of k_path_tree).
 // ------------------------------------------------------------------------------------------
 struct TraceResult { float t; int prim; bool occluded; uint32_t visits, tests; };
 

@@ -207,7 +207,7 @@ LR_DEV float det_fmod1_pos(float x) { return x - __builtin_floorf(x); }
 // 1.0f / d, correctly rounded, in five instructions instead of the compiler's ten (v_div_scale x2, v_rcp, 4 fma,
 // mul, v_div_fmas, v_div_fixup): v_rcp_f32 (1 ulp) and two Newton steps with fused residuals.  Bit-equal to the
 // IEEE quotient for every float with 2^-126 <= |d| < 2^126 (biased exponent 1..252) -- checked EXHAUSTIVELY by
-// lr_selftest_rcp (tests/test_gpu_parity.py::test_fast_reciprocal_is_ieee_exact).  The one user is the triangle
+// lr_selftest_rcp (tests/test_gpu_math.py::test_fast_reciprocal_is_ieee_exact).  The one user is the triangle
 // test's 1/det: it discards the value when |det| < 1e-3, and |det| <= |e1| |e2| |d| stays below 2^126 because
 // lr_scene_create refuses triangles with |e1| |e2| >= 2^120 (edges of ~1e18 units).  A guarded form with the
 // compiler's sequence as a wave-uniform fallback inside the loop cost 9 % of the frame, so the guard sits on the host.

@@ -14,11 +14,14 @@
 //              112-117), so per triangle  tv = o - p0,  qv = tv x e1  and  e2 . qv  (17 of the 57 operations of
 //              triangle.rs:69-100), per sphere  co  and  |co|^2,  and the scalar row loads are computed once for the pair.
 //              Every remaining operation keeps its operands and its order: the hits are the same bits.
-//   resolve    scene.rs:127-147 for the connection just tested
+//   settle     bvh.rs:20-25: the own box of what each of the two rays hit has the last word (lr_kernels.h own_box_unsure: one
+//              approximate slab test per winner; the rays it cannot settle are traced again literally)
+//   resolve    scene.rs:127-147 for the connection just tested (tree scenes: for the connection whose outcome the lane parked
+//              when its walk ended -- settle and resolve run at the lane's next vertex, where the wave's finished rays are densest)
 //   shade      scene.rs:153-193 (shade_vertex_core, the same function the other pipelines call)
 //
 // Same device functions, same RNG keys, same chunk order and the same order of additions into a sample's radiance as the
-// other pipelines => bit-identical films (tests/test_gpu_parity_r3.py).
+// other pipelines => bit-identical films (tests/test_gpu_pipelines.py).
 //
 // Work items come from a per-WAVE pool of four LDS words, topped up by one global atomic per 64 items.  Nothing that is only
 // needed at the finish stage is kept in a register across the walk (fresh_s / fresh_v, lr_kernels.h): in a persistent kernel
@@ -672,10 +675,12 @@ LR_DEV bool ptrav_prim(const DevScene& sc, PTrav& s, const LS& ls, bool conn, bo
   else hit = tri_test(v3(q0), v3(q1), v3(q2), o, d, &t);
 #endif
   if (!hit) return false;
+#if !LR_NO_LIT      // (LR_NO_LIT: measurement only -- what the literal-mode test costs the leaf loop: 1.7 % on config 4, 2.6 % on config 5)
   if (lit) { if (!own_box_exact(sc.pbox[kRecRows * (size_t)id], sc.pbox[kRecRows * (size_t)id + 1], o, d)) return false; }
+#endif
   if (CONN && conn) {
     float diff = t - ls.sh_d.v.w;
-    if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return true; }   // (the occluder: ptrav_settle looks at its own box)
+    if (diff < -kEps) { s.occluded = true; s.t = t; s.prim = id; return true; }   // (the occluder: its own box is settled at the lane's next vertex)
     if (diff > kEps) return false;
   }
   if (t < s.t || (t == s.t && id < s.prim)) { s.t = t; s.prim = id; }
@@ -756,6 +761,9 @@ LR_DEV void ptrav_burst(const DevScene& sc, PTrav& s, const LS& ls, bool conn, b
 
 #ifndef LR_FAKE_SETTLE
 #define LR_FAKE_SETTLE 0
+#endif
+#ifndef LR_NO_LIT
+#define LR_NO_LIT 0
 #endif
 // the outcome of a connection's walk in one word: 0 = nothing in the window, w + 1 = primitive w hit inside it, -(x + 1) = occluded by x
 LR_DEV uint32_t conn_word(const PTrav& s) { return s.prim < 0 ? 0u : (s.occluded ? (uint32_t)-(s.prim + 1) : (uint32_t)(s.prim + 1)); }

@@ -187,6 +187,14 @@ def _edge_rays(desc, n, seed):
     o = np.where(rng.random((n, 1)) < 0.3, cam[None, :], glo + rng.random((n, 3)) * (ghi - glo))
     dirs = tgt - o
     dirs /= np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-30)
+    # every 16th ray: axis-parallel, its origin exactly IN planes of the target's box (target snapped to faces, not perturbed): two
+    # direction components are zero and (plane - o) is zero on those axes -- the 0 * inf = NaN and +-inf cases of aabb.rs:74-92
+    ax = np.arange(n) % 16 == 0
+    b = rng.integers(0, 3, n)
+    e = np.eye(3)[b] * rng.choice([-1.0, 1.0], (n, 1))
+    snapped = np.where(snap == 0, lo[k], np.where(snap == 1, hi[k], lo[k] + f * (hi[k] - lo[k])))
+    o = np.where(ax[:, None], snapped - e * (rng.random((n, 1)) * 300.0 + 1.0), o)
+    dirs = np.where(ax[:, None], e, dirs)
     return o.astype(np.float32), dirs.astype(np.float32)
 
 STATED_SIZE = sorted(gc.STATED_SIZE_CASES)
