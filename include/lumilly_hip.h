@@ -110,7 +110,9 @@ typedef struct LrSky {
  * Two-child node carrying BOTH child boxes, one axis per 16-byte row so that one node fetch
  * tests two boxes.  A child reference c >= 0 is an inner node index; c < 0 is a leaf,
  * ~c = (first << 3) | count, covering prim_order[first .. first+count) with count in 0..7.
- * Boxes must be CONSERVATIVE (inflated, see lr_host_build_bvh); results never depend on them.
+ * Boxes must be CONSERVATIVE (inflated, see lr_host_build_bvh): they only decide how many primitive tests run.  What makes a
+ * primitive a CANDIDATE is the reference's own rule, evaluated by the library on the primitive's own exact box (bvh.rs:20-25:
+ * aabb.rs:74-92 must pass on it, seeded with [-1e5, 1e5]); the result is the closest hit over the candidates (bvh.rs:131-141).
  */
 typedef struct LrBvhNode {
   float   x[4];                      /* left.min.x, left.max.x, right.min.x, right.max.x     */
@@ -131,7 +133,10 @@ typedef struct LrSceneDesc {
   int32_t            n_bvh_nodes;    /* >= 1 (node 0 is the root); 0 with bvh_nodes == NULL: the library
                                         builds an LBVH on the device (replaces bvh.rs:56-127 there)   */
   const LrBvhNode*   bvh_nodes;
-  const int32_t*     bvh_prim_order; /* n_prims entries: leaf ranges index into this          */
+  const int32_t*     bvh_prim_order; /* n_prims entries: leaf ranges index into this.  ALSO the order that breaks exact distance
+                                        ties: bvh.rs:131-141 keeps the first minimum of a candidate list that bvh.rs:38-45 fills
+                                        depth-first, and lr_host_build_bvh emits the leaves in exactly that order (the reference's
+                                        SAH recursion with stable sorts).  A device-built tree breaks ties by primitive index      */
   int32_t            bvh_max_depth;  /* max number of inner nodes on a root-to-leaf path      */
 } LrSceneDesc;
 

@@ -64,9 +64,12 @@ int  lr_host_scene_bvh_info(const LrHostScene* scene, double* seconds, int* n_no
 /* JSON dump of the parsed Config + derived camera + per-primitive data; used by the loader tests. */
 int  lr_host_scene_dump_json(const LrHostScene* scene, int max_prims, char** out_json);
 
-/* Stand-alone SAH build over a primitive array (bvh.rs:56-127).  extra_point (3 floats, may be
- * NULL) is included in the scene extent that sizes the conservative box padding (camera position).
- * Outputs are malloc'd; release with lr_host_free. */
+/* Stand-alone SAH build over a primitive array (bvh.rs:56-127): the reference's recursion -- full sweep over the three axes,
+ * T = 2 T_aabb + (A(S1) N(S1) + A(S2) N(S2)) T_tri / A(S), decided on the primitives' exact boxes, the reference's sequence of
+ * sorts (stable) -- so that prim_order_out is the depth-first leaf order of the reference's tree, i.e. the candidate order of
+ * bvh.rs:38-45 that decides exact distance ties (bvh.rs:131-141 keeps the first minimum), also inside a leaf of up to max_leaf
+ * primitives.  The STORED boxes are padded (conservative).  extra_point (3 floats, may be NULL) is included in the scene extent
+ * that sizes the padding (camera position).  Outputs are malloc'd; release with lr_host_free. */
 int  lr_host_build_bvh(const LrPrimitive* prims, int n_prims, int max_leaf, const float* extra_point,
                        LrBvhNode** nodes_out, int* n_nodes_out, int32_t** prim_order_out, int* max_depth_out);
 void lr_host_free(void* p);

@@ -1982,14 +1982,31 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
   uint32_t tl_iter = 0, tl_iter_dry = 0;
 #endif
 #ifdef LR_STAMP
-  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #define LR_TICK(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tk[i] += t_now - t_prev; t_prev = t_now; }
+  // what per-slot ready flags could give back of the top barrier: phase 3 stamps every slot it completes (sh_d[slot].x is
+  // dead then); after the barrier a wave takes the newest stamp among ITS 64 slots: the part of its wait that came after that is tk[6]
+#define LR_READY_STAMP(ok, slot) { if (ok) ((float*)(lds4 + 4 * RB))[4 * (slot)] = __uint_as_float((uint32_t)__builtin_amdgcn_s_memtime() | 1u); }
 #else
 #define LR_TICK(i)
+#define LR_READY_STAMP(ok, slot)
 #endif
   while (true) {
+#ifdef LR_STAMP
+    const unsigned long long t_arrive = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                                                // previous iteration (or generation) complete
     LR_TICK(0)
+#ifdef LR_STAMP
+    {
+      const uint32_t stamp = __float_as_uint(((float*)(lds4 + 4 * RB))[4 * tid]);
+      ((float*)(lds4 + 4 * RB))[4 * tid] = 0.0f;
+      uint32_t age = (stamp & 1u) ? (uint32_t)t_prev - stamp : 0x7fffffffu;        // cycles since the slot's phase-3 work completed
+      for (int o = 32; o > 0; o >>= 1) { uint32_t x = (uint32_t)__shfl_xor((int)age, o, 64); age = x < age ? x : age; }
+      const uint32_t waited = (uint32_t)(t_prev - t_arrive);
+      tk[6] += age < waited ? age : waited;
+    }
+#endif
     const uint32_t retired = s_retired;
 #ifdef LR_TIMELINE
     tl_iter += 1;
@@ -2070,6 +2087,7 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
           else r = traverse<true>(sc, o, dir, sd.w, stk_n, nullptr);
           n_shq += 1;
           shadow_resolve(sc, st, slot, o, dir, r);
+          LR_READY_STAMP(true, slot)
         }
       } else {
         uint32_t i = (v - wsh) * 64u + lane;
@@ -2087,13 +2105,14 @@ __global__ void __launch_bounds__(RB, LR_RES_WAVES) k_resident(DevScene sc, DevS
         }
         bool rr = finish_and_regenerate(sc, st, rp, &pl, slot, valid, false, L, g, pixel, sample);
         (void)wave_reserve(&s_retired, rr);
+        LR_READY_STAMP(valid, slot)
       }
     }
     LR_TICK(4)
   }
 #ifdef LR_STAMP
   // diagnostic build only: lane 0 of every wave adds its cycle shares to the tail of the stats buffer
-  if (lane_id() == 0) for (int i = 0; i < 6; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
+  if (lane_id() == 0) for (int i = 0; i < 7; ++i) atomicAdd(gst.stats + (size_t)kStatShards * kStatStride + i, tk[i]);
 #endif
   LR_TL(gst, 2)
 #ifdef LR_TIMELINE

@@ -1135,6 +1135,8 @@ void render_impl(LrScene& s, const LrRenderParams& rp_in, const LrTile* tiles, i
     double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)tk[i];
     std::fprintf(stderr, "[LR_STAMP] k_resident wave-cycle shares: trace %.1f%% + barrier %.1f%%  shade %.1f%% + barrier %.1f%%  shadow / finish %.1f%% + barrier %.1f%%\n",
                  100 * tk[2] / tot, 100 * tk[1] / tot, 100 * tk[3] / tot, 100 * tk[5] / tot, 100 * tk[4] / tot, 100 * tk[0] / tot);
+    std::fprintf(stderr, "[LR_STAMP] of the last barrier, %.2f%% of all wave cycles came after every one of the wave's own 64 slots had completed phase 3 (what per-slot ready flags could return)\n",
+                 100 * tk[6] / tot);
   }
 #endif
 #ifdef LR_DIAG
