@@ -573,6 +573,47 @@ def test_stated_size_tiles_against_the_live_oracle(dev, oracle, key):
 
 
 @pytest.mark.parametrize("key", STATED_SIZE)
+def test_whole_stated_frame_against_the_live_oracle(dev, oracle, key):
+    """EVERY pixel of a stated frame (main.rs:80-122 runs per pixel of the W x H film) against the oracle's reference-literal mode, at the stated
+    spp: per-pixel bar, equal counters.  Minutes of host time per config (configs[1]: 1.07e9 samples, ~90 s on 16 cores; configs[4]: 3.4e10, ~50
+    min), so opt-in: LUMILLY_WHOLE_FRAMES=c2,c3 selects the configs; LUMILLY_RECORD=<dir> keeps a one-line record of what was compared
+    (profiles/r06_whole_frame_<config>.json are such records)."""
+    import json, time
+    if key not in os.environ.get("LUMILLY_WHOLE_FRAMES", "").split(","):
+        pytest.skip("opt-in: LUMILLY_WHOLE_FRAMES=" + key)
+    name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES[key]
+    if gen and not gc.have_generated_assets():
+        pytest.skip("generated assets missing")
+    desc = gc.load_scene(name, edit, w, h)
+    p = desc.render_params(spp=spp, seed=seed, integrator=integ)
+    scene = dev.Scene(desc)
+    img = scene.render(p)
+    st = scene.stats()
+    dev_ms = st.render_ms
+    scene.close()
+    t0 = time.perf_counter()
+    ref, so = oracle.render(desc, p, mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
+    cpu_s = time.perf_counter() - t0
+    both_nan = np.isnan(img) & np.isnan(ref)
+    ok = _within_bar(img, ref) | both_nan
+    diff = np.where(both_nan, 0.0, np.abs(img - ref))
+    rec = {"config": key, "scene": name, "edit": edit, "width": w, "height": h, "spp": spp, "integrator": integ, "seed": seed,
+           "pixels": w * h, "samples": int(st.samples), "oracle_mode": "BVH (reference-literal: SAH tree, every overlapped leaf whose own box passes, first minimum), pad 0",
+           "pixels_over_the_bar": int((~ok).any(axis=2).sum()), "pixels_differing_at_all": int((_bits(img) != _bits(ref)).any(axis=2).sum()),
+           "pixels_nan_in_both": int(both_nan.any(axis=2).sum()), "max_abs_diff": float(np.nanmax(diff)),
+           "max_diff_over_bar_unit": float(np.nanmax(diff / (TOL * np.maximum(1.0, np.abs(np.where(both_nan, 1.0, ref)))))),
+           "counters_device": [int(x) for x in _counters(st)], "counters_oracle": [int(so.samples), int(so.segments), int(so.shadow_rays), int(so.sky_fetches)],
+           "device_render_ms": round(dev_ms, 2), "oracle_seconds": round(cpu_s, 1), "build": dev.build_info()}
+    out = os.environ.get("LUMILLY_RECORD")
+    if out:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"whole_frame_{key}.json"), "w") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert rec["counters_device"] == rec["counters_oracle"], rec
+    assert ok.all(), rec
+
+
+@pytest.mark.parametrize("key", STATED_SIZE)
 def test_stated_size_tiles_against_the_fixtures(dev, key):
     """The same renders against the committed fixtures (tests/golden/stated_<config>.npy: the tiles' pixels in tile order, written by
     tests/golden/make_golden.py with the oracle) -- no oracle in the process."""
