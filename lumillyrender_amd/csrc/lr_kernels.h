@@ -1539,7 +1539,17 @@ LR_DEV VertexOut shade_vertex_core(const DevScene& sc, ST& st, const DevParams& 
         coef = material_coef<MT>(m, out_, nrm, t);
       }
       float c = dot(in_, nrm);
-      V3 f = brdf * coef * (c * rcp_r(pdf * p));
+      const float q = pdf * p;
+      V3 f;
+      if (__builtin_expect(!(__builtin_fabsf(q) >= 1.17549435e-38f), 0)) {
+        // a pdf in the DENORMAL range (or 0 / NaN): a Phong / Blinn-Phong direction almost across the lobe, c^20 ~ 1e-40 -- six samples of the
+        // 2.1e9 of the stated row.  v_rcp_f32 reads a denormal as 0 and returns inf, where scene.rs:101's `brdf * coef * L_i * cos / pdf` -- the
+        // BRDF value as small as the pdf that divides it -- is finite (found by the whole-frame check against the literal restatement):
+        // the reference's operations in its order, IEEE divisions (cold)
+        f = ((brdf * coef) * c) / pdf / p;
+      } else {
+        f = brdf * coef * (c * rcp_r(q));
+      }
       T = T * f;
       st.ray_o[slot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(depth + 1));
       st.ray_d[slot] = make_float4(in_.x, in_.y, in_.z, out.g_term);
