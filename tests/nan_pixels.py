@@ -1,5 +1,5 @@
 """Which pixels of a Phong / Blinn-Phong row are NaN on one side only (device vs the literal oracle), and from which sample on.
-A test-side probe (it calls the oracle): run from tests' environment on the GPU box:  python tools/nan_pixels.py c3p"""
+A test-side probe (it calls the oracle, so it lives under tests/); on the GPU box:  python tests/nan_pixels.py c3p"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
