@@ -605,19 +605,25 @@ def test_whole_stated_frame_against_the_live_oracle(dev, oracle, key):
         pytest.skip("generated assets missing")
     desc = gc.load_scene(name, edit, w, h)
     p = desc.render_params(spp=spp, seed=seed, integrator=integ)
+    # LUMILLY_WHOLE_BAND="k/n": rows [k h / n, (k + 1) h / n) only -- a frame that takes an hour of oracle time in n calls
+    band_k, band_n = (int(v) for v in os.environ.get("LUMILLY_WHOLE_BAND", "0/1").split("/"))
+    y0, y1 = band_k * h // band_n, (band_k + 1) * h // band_n
+    from lumillyrender_amd import abi
+    t = (abi.LrTile * 1)(); t[0].x0, t[0].y0, t[0].w, t[0].h = 0, y0, w, y1 - y0
     scene = dev.Scene(desc)
-    img = scene.render(p)
+    img = scene.render(p, t, 1)[y0:y1]
     st = scene.stats()
     dev_ms = st.render_ms
     scene.close()
     t0 = time.perf_counter()
-    ref, so = oracle.render(desc, p, mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
+    ref, so = oracle.render(desc, p, t, 1, mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
+    ref = ref[y0:y1]
     cpu_s = time.perf_counter() - t0
     both_nan = np.isnan(img) & np.isnan(ref)
     ok = _within_bar(img, ref) | both_nan
     diff = np.where(both_nan, 0.0, np.abs(img - ref))
     rec = {"config": key, "scene": name, "edit": edit, "width": w, "height": h, "spp": spp, "integrator": integ, "seed": seed,
-           "pixels": w * h, "samples": int(st.samples), "oracle_mode": "BVH (reference-literal: SAH tree, every overlapped leaf whose own box passes, first minimum), pad 0",
+           "rows": [y0, y1], "pixels": w * (y1 - y0), "samples": int(st.samples), "oracle_mode": "BVH (reference-literal: SAH tree, every overlapped leaf whose own box passes, first minimum), pad 0",
            "pixels_over_the_bar": int((~ok).any(axis=2).sum()), "pixels_differing_at_all": int((_bits(img) != _bits(ref)).any(axis=2).sum()),
            "pixels_nan_in_both": int(both_nan.any(axis=2).sum()), "max_abs_diff": float(np.nanmax(diff)),
            "max_diff_over_bar_unit": float(np.nanmax(diff / (TOL * np.maximum(1.0, np.abs(np.where(both_nan, 1.0, ref)))))),
@@ -626,7 +632,7 @@ def test_whole_stated_frame_against_the_live_oracle(dev, oracle, key):
     out = os.environ.get("LUMILLY_RECORD")
     if out:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, f"whole_frame_{key}.json"), "w") as f:
+        with open(os.path.join(out, f"whole_frame_{key}.json" if band_n == 1 else f"whole_frame_{key}_band{band_k}of{band_n}.json"), "w") as f:
             f.write(json.dumps(rec) + "\n")
     assert rec["counters_device"] == rec["counters_oracle"], rec
     assert ok.all(), rec
