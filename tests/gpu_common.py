@@ -217,3 +217,15 @@ def p_w(desc):
 
 def p_h(desc):
     return int(desc.desc.camera.resolution[1])
+
+
+def usable_cores():
+    """Host threads the oracle should start: the affinity mask capped by the cgroup CPU quota (256 threads against a 16-core quota run at half the rate)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return cores

@@ -616,7 +616,7 @@ def test_whole_stated_frame_against_the_live_oracle(dev, oracle, key):
     dev_ms = st.render_ms
     scene.close()
     t0 = time.perf_counter()
-    ref, so = oracle.render(desc, p, t, 1, mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
+    ref, so = oracle.render(desc, p, t, 1, threads=usable_cores(), mode=oracle.BVH, pad=0.0, with_stats=True, fast=True)
     ref = ref[y0:y1]
     cpu_s = time.perf_counter() - t0
     both_nan = np.isnan(img) & np.isnan(ref)
@@ -628,7 +628,7 @@ def test_whole_stated_frame_against_the_live_oracle(dev, oracle, key):
            "pixels_nan_in_both": int(both_nan.any(axis=2).sum()), "max_abs_diff": float(np.nanmax(diff)),
            "max_diff_over_bar_unit": float(np.nanmax(diff / (TOL * np.maximum(1.0, np.abs(np.where(both_nan, 1.0, ref)))))),
            "counters_device": [int(x) for x in _counters(st)], "counters_oracle": [int(so.samples), int(so.segments), int(so.shadow_rays), int(so.sky_fetches)],
-           "device_render_ms": round(dev_ms, 2), "oracle_seconds": round(cpu_s, 1), "build": dev.build_info()}
+           "device_render_ms": round(dev_ms, 2), "oracle_seconds": round(cpu_s, 1), "oracle_threads": usable_cores(), "build": dev.build_info()}
     out = os.environ.get("LUMILLY_RECORD")
     if out:
         os.makedirs(out, exist_ok=True)

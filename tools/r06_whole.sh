@@ -3,4 +3,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06w
 export LUMILLY_WHOLE_FRAMES=$(echo $1 | tr ' ' ',') LUMILLY_RECORD=gpurun_out/r06w LUMILLY_WHOLE_BAND=${2:-0/1}
-timeout 6500 python -m pytest tests/test_gpu_film.py -q -m gpu -k whole_stated_frame 2>&1 | tail -25 > gpurun_out/r06w/whole_$(echo $1 | tr ' ' '_')_$(echo ${2:-0/1} | tr '/' 'of').log
+timeout 6500 python -m pytest tests/test_gpu_film.py -q -m gpu -k whole_stated_frame 2>&1 | tail -25 > gpurun_out/r06w/whole_$(echo $1 | tr ' ' '_')_$(echo ${2:-0/1} | sed 's:/:of:').log
