@@ -117,8 +117,23 @@ def functions():
     print(gc.FUNCTIONS, {k: v.shape for k, v in out.items()})
 
 
+def denormal_pdf_pixels():
+    """golden_cases.DENORMAL_PDF_PIXELS: the oracle's value of each pixel after samples 0 .. k of the stated Phong row (finite: scene.rs:101
+    divides a denormal BRDF value by a denormal pdf)."""
+    name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES["c3p"]
+    d = gc.load_scene(name, edit, w, h)
+    out = np.zeros((len(gc.DENORMAL_PDF_PIXELS), 3), dtype=np.float32)
+    for i, (x, y, k) in enumerate(gc.DENORMAL_PDF_PIXELS):
+        out[i] = oracle.render(d, d.render_params(spp=k + 1, seed=seed, integrator=integ), gc.one_pixel_tile(x, y), 1, mode=oracle.BVH, pad=0.0)[y, x]
+    path = os.path.join(gc.GOLDEN, gc.DENORMAL_PDF_FIXTURE)
+    np.save(path, out)
+    print(path, out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["films", "stated_spp", "stated_size", "functions"]
+    what = sys.argv[1:] or ["films", "stated_spp", "stated_size", "functions", "denormal_pdf"]
+    if "denormal_pdf" in what:
+        denormal_pdf_pixels()
     if "films" in what:
         films()
     if "stated_spp" in what:

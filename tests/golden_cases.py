@@ -127,6 +127,21 @@ def stated_name(key):
     return f"stated_{key}.npy"
 
 
+# phong.rs:47-68 at alpha = 20: the six pixels of the stated Phong row (960 x 540 x 4096 spp, seed 0) in which one sample draws a direction
+# whose pdf 22 / 2 pi * c^20 is a DENORMAL (not 0): (x, y, index of that sample).  scene.rs:101 divides the equally small BRDF value by it and
+# stays finite; found by the whole-frame check of round 6 (a hardware reciprocal reads a denormal as 0).  The fixture holds the oracle's
+# pixel after samples 0 .. k (RNG keys are (pixel, sample): a prefix of the stated samples).
+DENORMAL_PDF_PIXELS = [(580, 182, 1081), (510, 268, 3170), (291, 291, 1513), (544, 358, 3795), (432, 424, 3584), (476, 477, 3223)]
+DENORMAL_PDF_FIXTURE = "denormal_pdf_c3p.npy"
+
+
+def one_pixel_tile(x, y):
+    from lumillyrender_amd import abi
+    t = (abi.LrTile * 1)()
+    t[0].x0, t[0].y0, t[0].w, t[0].h = int(x), int(y), 1, 1
+    return t
+
+
 def film_name(case):
     name, edit, w, h, spp, integ, seed, _ = case
     tag = "" if edit is None else "_" + edit

@@ -136,6 +136,17 @@ def test_oracle_reproduces_the_stated_size_tiles(key):
     assert st.samples == len(ref) * spp and len(ref) >= 16384
 
 
+def test_oracle_keeps_a_denormal_pdf_finite():
+    """golden_cases.DENORMAL_PDF_PIXELS: the oracle reproduces the fixture bit for bit, and every value is finite (the pdf is denormal, not 0)."""
+    name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES["c3p"]
+    d = gc.load_scene(name, edit, w, h)
+    ref = np.load(os.path.join(gc.GOLDEN, gc.DENORMAL_PDF_FIXTURE))
+    assert ref.shape == (len(gc.DENORMAL_PDF_PIXELS), 3) and np.isfinite(ref).all() and (ref > 0).all()
+    for i, (x, y, k) in enumerate(gc.DENORMAL_PDF_PIXELS):
+        got = oracle.render(d, d.render_params(spp=k + 1, seed=seed, integrator=integ), gc.one_pixel_tile(x, y), 1, mode=oracle.BVH, pad=0.0)[y, x]
+        assert np.array_equal(got.view(np.uint32), ref[i].view(np.uint32)), (x, y, k, got, ref[i])
+
+
 def test_stated_tiles_are_disjoint_and_inside_the_film():
     for key, (name, edit, w, h, spp, integ, seed, gen, rows) in gc.STATED_SIZE_CASES.items():
         tl = gc.stated_tiles(w, h, rows)

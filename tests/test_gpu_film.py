@@ -577,17 +577,17 @@ def test_a_denormal_pdf_keeps_its_sample_finite(dev, oracle):
     the reference's own NaN) and a BRDF value just as small; scene.rs:101 divides one by the other and gets a finite weight.  A 1-ulp hardware
     reciprocal reads a denormal as 0 -> inf -> NaN pixel.  The six pixels of the stated Phong row (960 x 540 x 4096 spp, seed 0) where the whole-frame
     check found it, each rendered up to and including the sample in question (RNG keys are (pixel, sample): a prefix of the stated samples)."""
-    from lumillyrender_amd import abi
     name, edit, w, h, spp, integ, seed, gen, rows = gc.STATED_SIZE_CASES["c3p"]
     desc = gc.load_scene(name, edit, w, h)
     scene = dev.Scene(desc)
-    for x, y, k in [(580, 182, 1081), (510, 268, 3170), (291, 291, 1513), (544, 358, 3795), (432, 424, 3584), (476, 477, 3223)]:
-        t = (abi.LrTile * 1)(); t[0].x0, t[0].y0, t[0].w, t[0].h = x, y, 1, 1
+    fixture = np.load(os.path.join(gc.GOLDEN, gc.DENORMAL_PDF_FIXTURE))          # the oracle's values, pinned on CPU by tests/test_golden_fixtures.py
+    for i, (x, y, k) in enumerate(gc.DENORMAL_PDF_PIXELS):
+        t = gc.one_pixel_tile(x, y)
         p = desc.render_params(spp=k + 1, seed=seed, integrator=integ)
         got = scene.render(p, t, 1)[y, x]
         ref = oracle.render(desc, p, t, 1, mode=oracle.BVH, pad=0.0)[y, x]
         assert np.isfinite(ref).all() and np.isfinite(got).all(), (x, y, k, got, ref)
-        assert _within_bar(got, ref).all(), (x, y, k, got, ref)
+        assert _within_bar(got, ref).all() and _within_bar(got, fixture[i]).all(), (x, y, k, got, ref, fixture[i])
     scene.close()
 
 
